@@ -1,0 +1,70 @@
+// fe_common.h -- shared device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fe {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define FE_AS1 __attribute__((address_space(1)))
+#define FE_AS3 __attribute__((address_space(3)))
+
+// 32-bit LDS byte address of a generic pointer into __shared__ memory, made
+// provably wave-uniform (it is moved into M0 by the LDS-DMA helpers).
+__device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {
+    unsigned a = (unsigned)(uintptr_t)(FE_AS3 const void*)p;
+    return __builtin_amdgcn_readfirstlane(a);
+}
+
+// LDS-DMA ("global_load_lds"): each active lane copies 16 (or 4) bytes from its
+// own global address `g` to LDS at  lds_base + lane*size  (destination is
+// lane-linear: wave-uniform base in M0).  Issued through inline asm so that
+// hipcc's waitcnt pass does not see the loads and does not drain them with a
+// vmcnt(0) in front of the first ds_read of a *different* staging buffer; the
+// kernels wait for them with counted `s_waitcnt vmcnt(N)` (see wait_vmcnt).
+// M0 is compiler-reserved: save and restore it inside the statement.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);   // "s" needs a provably uniform value
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_base)
+        : "memory");
+}
+__device__ __forceinline__ void glds4(const void* g, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_base)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Orders this wave's LDS accesses for the compiler.  The hardware executes one
+// wave's DS instructions in issue order, so wave-private LDS staging needs no
+// s_barrier -- only a compiler fence between the writes of some lanes and the
+// reads of others.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace fe

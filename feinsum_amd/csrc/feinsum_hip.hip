@@ -1,0 +1,311 @@
+// feinsum_hip.hip -- C ABI of libfeinsum_hip.so (see include/feinsum_hip.h).
+// gfx950 only.  Host side: argument validation, kernel-variant dispatch (the
+// build's replacement for feinsum's transform archive lookup,
+// sql_utils.py:247-294) and asynchronous launches on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/feinsum_hip.h"
+#include "fe_common.h"
+#include "fe_div.h"
+#include "fe_facemass.h"
+#include "fe_generic.h"
+#include "fe_grad.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define FE_HIP_CHECK(expr)                                                             \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(FE_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+    } while (0)
+
+// Persistent-style grid: enough blocks to fill every CU at the kernel's
+// residency (2 blocks of 256 threads per CU), capped by the work available.
+int device_cu_count() {
+    static int cus[64];
+    static std::once_flag once[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::call_once(once[dev], [dev] {
+        hipDeviceProp_t p;
+        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                       ? p.multiProcessorCount
+                       : 256;
+    });
+    return cus[dev];
+}
+
+template <typename K>
+int set_max_lds(K kernel, int bytes) {
+    FE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return FE_OK;
+}
+
+int check_common(const void* J, const void* D, const void* u, const void* out, int64_t E,
+                 int32_t Np) {
+    if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
+    if (Np <= 0) return fail(FE_EINVAL, "Np must be positive (got %d)", Np);
+    if (E > 0 && (!J || !D || !u || !out)) return fail(FE_EINVAL, "null device pointer");
+    if (E * (int64_t)Np >= (int64_t)1 << 39)
+        return fail(FE_EINVAL, "E*Np too large (%lld)", (long long)(E * Np));
+    return FE_OK;
+}
+
+unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 256); }
+
+// Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
+// CU (their VGPR / LDS residency), fewer when there is less work.
+unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
+    int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
+    const int64_t cap = 2 * (int64_t)device_cu_count();
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fe_version(void) { return 1000; }
+
+const char* fe_last_error(void) { return g_err; }
+
+int fe_device_count(void) {
+    int n = 0;
+    FE_HIP_CHECK(hipGetDeviceCount(&n));
+    return n;
+}
+
+int fe_device_info(int dev, char* name, size_t name_len, double* peak_f64_gflops,
+                   double* peak_gbps) {
+    hipDeviceProp_t p;
+    FE_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    if (name && name_len) {
+        strncpy(name, p.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    // fp64: vector = matrix = 32 FMA-flop/clk/SIMD.. i.e. 128 flop/clk/CU (MI355X: 256 CUs
+    // x 2.4 GHz -> 78.6 TFLOP/s); HBM3E 8 TB/s (datasheet).  gfx950 only.
+    const bool mi355 = strstr(p.gcnArchName, "gfx950") != nullptr;
+    if (peak_f64_gflops)
+        *peak_f64_gflops = mi355 ? 128.0 * p.multiProcessorCount * (p.clockRate * 1e-6) : 0.0;
+    if (peak_gbps) *peak_gbps = mi355 ? 8000.0 : 0.0;
+    return FE_OK;
+}
+
+int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp, int32_t b) {
+    const int64_t np = Np;
+    switch (family) {
+        case FE_FAMILY_GRAD:
+        case FE_FAMILY_DIV: return 2 * 3 * np * np + 2 * 9 * np;
+        case FE_FAMILY_GRADDIV: return 2 * (2 * 3 * np * np + 2 * 9 * np);
+        case FE_FAMILY_FACEMASS: return (int64_t)b * ((int64_t)nf * Nfp + 2 * np * nf * Nfp);
+        default: return -1;
+    }
+}
+
+int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
+                  int32_t Np, int32_t variant, void* stream) {
+    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool mfma_ok = (Np == fe::kNp35);
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np == 35 only (Np=%d)", Np);
+    int64_t e_done = 0;
+    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+        const int64_t nTiles = E / fe::kTE;   // full tiles; the remainder goes to the generic kernel
+        if (nTiles > 0) {
+            static std::once_flag once;
+            static int attr_rc = FE_OK;
+            std::call_once(once, [] { attr_rc = set_max_lds(fe::grad3d_np35_mfma_kernel, fe::kGradLdsBytes); });
+            if (attr_rc != FE_OK) return attr_rc;
+            hipLaunchKernelGGL(fe::grad3d_np35_mfma_kernel, dim3(persistent_grid(nTiles, fe::kGradWavesPerBlock)),
+                               dim3(256), fe::kGradLdsBytes, s, J, D, u, out, E, nTiles);
+            e_done = nTiles * fe::kTE;
+        }
+    }
+    if (e_done < E)
+        hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
+                           J, D, u, out, E, Np, e_done);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+int fe_div3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
+                 int32_t Np, int32_t variant, void* stream) {
+    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool mfma_ok = fe::div_mfma_supported(Np);
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "div: MFMA variant is compiled for Np == 35 only (Np=%d)", Np);
+    int64_t e_done = 0;
+    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+        const int64_t nTiles = E / fe::kTE;
+        if (nTiles > 0) {
+            static std::once_flag once;
+            static int attr_rc = FE_OK;
+            std::call_once(once, [] { attr_rc = set_max_lds(fe::div3d_np35_mfma_kernel, fe::kDivLdsBytes); });
+            if (attr_rc != FE_OK) return attr_rc;
+            hipLaunchKernelGGL(fe::div3d_np35_mfma_kernel, dim3(persistent_grid(nTiles, fe::kDivWavesPerBlock)),
+                               dim3(256), fe::kDivLdsBytes, s, J, D, u, out, E, nTiles);
+            e_done = nTiles * fe::kTE;
+        }
+    }
+    if (e_done < E)
+        hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
+                           J, D, u, out, E, Np, e_done);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, const double* v_div,
+                     double* grad_out, double* div_out, int64_t E, int32_t Np, int32_t variant,
+                     void* stream) {
+    // Two launches back to back on one stream: J (72 B/element) and D stay in
+    // L2 / Infinity Cache between them only for small E; see DESIGN.md.
+    if (int rc = fe_grad3d_f64(J, D, u_grad, grad_out, E, Np, variant, stream)) return rc;
+    return fe_div3d_f64(J, D, v_div, div_out, E, Np, variant, stream);
+}
+
+int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
+                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                    int32_t layout_flags, int32_t variant, void* stream) {
+    if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
+    if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
+        return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
+                    Nfp, b);
+    if (layout_flags & ~3) return fail(FE_EINVAL, "face-mass: bad layout flags %d", layout_flags);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "face-mass: unknown variant %d", variant);
+    if (!v || !out) return fail(FE_EINVAL, "face-mass: null pointer table");
+    if (E == 0) return FE_OK;
+    if (!J || !R) return fail(FE_EINVAL, "face-mass: null device pointer");
+    for (int k = 0; k < b; ++k)
+        if (!v[k] || !out[k]) return fail(FE_EINVAL, "face-mass: null field pointer %d", k);
+    if (E * (int64_t)Np >= (int64_t)1 << 39) return fail(FE_EINVAL, "E*Np too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const bool mfma_ok = fe::facemass_mfma_supported(Np, nf, Nfp, b);
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED,
+                    "face-mass: MFMA variant is compiled for Np=35 nf=4 Nfp=15 and b >= 2 only");
+    const int jfe = (layout_flags & FE_FM_J_FE) ? 1 : 0, rifj = (layout_flags & FE_FM_R_IFJ) ? 1 : 0;
+    const int64_t jEs = jfe ? 1 : nf, jFs = jfe ? E : 1;
+    const int rF = rifj ? Nfp : Np * Nfp, rI = rifj ? nf * Nfp : Nfp;
+    const bool use_mfma = variant != FE_VARIANT_GENERIC && mfma_ok;
+    const int64_t nTiles = use_mfma ? E / fe::kTE : 0;
+    const int64_t e_done = nTiles * fe::kTE;
+    if (nTiles > 0) {
+        static std::once_flag once;
+        static int attr_rc = FE_OK;
+        std::call_once(once, [] {
+#define FE_FM_ATTR(NB) if (attr_rc == FE_OK) attr_rc = set_max_lds(fe::facemass_np35_mfma_kernel<NB>, fe::kFmLdsBytes);
+            FE_FM_ATTR(2) FE_FM_ATTR(3) FE_FM_ATTR(4) FE_FM_ATTR(5) FE_FM_ATTR(6) FE_FM_ATTR(7) FE_FM_ATTR(8)
+#undef FE_FM_ATTR
+        });
+        if (attr_rc != FE_OK) return attr_rc;
+    }
+    // fields go in groups of up to 8 per launch; never leave a group of 1 for the MFMA kernel
+    for (int k0 = 0; k0 < b;) {
+        int nb = (b - k0 < fe::kMaxFields) ? b - k0 : fe::kMaxFields;
+        if (b - k0 - nb == 1) nb -= 1;
+        fe::FieldPtrs P;
+        for (int k = 0; k < fe::kMaxFields; ++k) {
+            P.v[k] = v[k0 + (k < nb ? k : 0)];
+            P.out[k] = out[k0 + (k < nb ? k : 0)];
+        }
+        const dim3 block(256);
+        if (nTiles > 0) {
+            const dim3 grid(persistent_grid(nTiles, fe::kFmWavesPerBlock));
+#define FE_FM_CASE(NB)                                                                             \
+    case NB:                                                                                       \
+        hipLaunchKernelGGL(fe::facemass_np35_mfma_kernel<NB>, grid, block, fe::kFmLdsBytes, s, J,  \
+                           R, P, E, nTiles, jfe, rifj);                                            \
+        break;
+            switch (nb) {
+                FE_FM_CASE(2) FE_FM_CASE(3) FE_FM_CASE(4) FE_FM_CASE(5)
+                FE_FM_CASE(6) FE_FM_CASE(7) FE_FM_CASE(8)
+                default: return fail(FE_EINVAL, "face-mass: internal field grouping error");
+            }
+#undef FE_FM_CASE
+        }
+        if (e_done < E) {
+            const dim3 grid(generic_grid(E - e_done, Np));
+#define FE_FM_CASE(NB)                                                                             \
+    case NB:                                                                                       \
+        hipLaunchKernelGGL(fe::facemass_generic_kernel<NB>, grid, block, 0, s, J, R, P, E, Np, nf, \
+                           Nfp, jEs, jFs, rF, rI, e_done);                                         \
+        break;
+            switch (nb) {
+                FE_FM_CASE(1) FE_FM_CASE(2) FE_FM_CASE(3) FE_FM_CASE(4)
+                FE_FM_CASE(5) FE_FM_CASE(6) FE_FM_CASE(7) FE_FM_CASE(8)
+            }
+#undef FE_FM_CASE
+        }
+        k0 += nb;
+    }
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
+    switch (family) {
+        case FE_FAMILY_GRAD:
+            return fe_grad3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->variant, stream);
+        case FE_FAMILY_DIV:
+            return fe_div3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->variant, stream);
+        case FE_FAMILY_GRADDIV:
+            return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
+                                    a->variant, stream);
+        case FE_FAMILY_FACEMASS:
+            return fe_facemass_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->nf, a->Nfp, a->b,
+                                   a->layout_flags, a->variant, stream);
+        default: return fail(FE_EINVAL, "unknown family %d", family);
+    }
+}
+
+int fe_time_launches(int32_t family, const fe_argpack* args, int32_t n_launches, void* stream,
+                     float* ms_out) {
+    if (!args || !ms_out || n_launches <= 0)
+        return fail(FE_EINVAL, "fe_time_launches: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t t0, t1;
+    FE_HIP_CHECK(hipEventCreate(&t0));
+    FE_HIP_CHECK(hipEventCreate(&t1));
+    int rc = FE_OK;
+    hipError_t e = hipEventRecord(t0, s);
+    for (int i = 0; i < n_launches && rc == FE_OK && e == hipSuccess; ++i)
+        rc = launch_family(family, args, stream);
+    if (e == hipSuccess) e = hipEventRecord(t1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(t1);
+    if (e == hipSuccess && rc == FE_OK) e = hipEventElapsedTime(ms_out, t0, t1);
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+    if (rc != FE_OK) return rc;
+    if (e != hipSuccess) return fail(FE_EHIP, "fe_time_launches: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
+}  // extern "C"

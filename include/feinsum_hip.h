@@ -1,0 +1,145 @@
+/*
+ * feinsum_hip.h -- C ABI of libfeinsum_hip.so, the MI355X (gfx950) evaluation
+ * backend for the 3D DG-wave batched einsums (grad / div / face-mass).
+ *
+ * This is the drop-in boundary.  The reference (kaushikcfd/feinsum) has no FFI
+ * seam of its own: its narrowest waist is the loopy executor call inside
+ *   feinsum/measure.py:163-165  (validate_batched_einsum_transform)
+ *   feinsum/measure.py:243-251,267 (timeit)
+ * i.e. ``evt, outs = t_unit.executor(cq, **arg_dict)(cq, **arg_dict)`` --
+ * "run the kernel generated for this BatchedEinsum on these device arrays,
+ * asynchronously on this queue".  Every fe_*_f64 launcher below replaces that
+ * call for one einsum family; fe_time_launches replaces the 5-launch timing
+ * batches of measure.py:260-273; fe_device_info replaces ``cq.device.name`` +
+ * feinsum/data/device_info.py:5-26.
+ *
+ * Conventions (all launchers):
+ *   - all pointers are DEVICE pointers to C-contiguous float64 arrays;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); nothing is allocated, no ownership moves:
+ *     the caller keeps every buffer alive until it synchronises the stream;
+ *   - inputs are read-only, outputs are fully overwritten (the reference's
+ *     kernels assign, they do not accumulate: codegen/loopy.py:289-305);
+ *   - E is the "long" element axis (feinsum SizeParam, einsum.py:26-41);
+ *     E == 0 is a valid no-op;
+ *   - return 0 on success, a negative FE_E* code otherwise; the message is
+ *     available from fe_last_error() (thread-local).
+ *   - thread-safety: re-entrant; distinct streams may be driven from distinct
+ *     host threads.  No global mutable state besides an init-once attribute
+ *     cache.
+ *
+ * `variant` selects the kernel implementation (the build's replacement for the
+ * reference's transform archive lookup, sql_utils.py:247-294):
+ *   FE_VARIANT_AUTO    best available kernel for (Np, alignment)
+ *   FE_VARIANT_GENERIC plain one-thread-per-output VALU kernel, any Np
+ *   FE_VARIANT_MFMA    LDS-staged fp64-MFMA kernel (needs Np == 35 etc.;
+ *                      FE_EUNSUPPORTED if the shape is not compiled)
+ */
+#ifndef FEINSUM_HIP_H
+#define FEINSUM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FE_OK            0
+#define FE_EINVAL       -1  /* bad shape / null pointer / negative size      */
+#define FE_EUNSUPPORTED -2  /* (Np, variant, layout) not compiled            */
+#define FE_EHIP         -3  /* HIP runtime error, text in fe_last_error()    */
+
+#define FE_VARIANT_AUTO    0
+#define FE_VARIANT_GENERIC 1
+#define FE_VARIANT_MFMA    2
+
+/* families, for fe_time_launches / fe_flops_per_element */
+#define FE_FAMILY_GRAD     1
+#define FE_FAMILY_DIV      2
+#define FE_FAMILY_GRADDIV  3
+#define FE_FAMILY_FACEMASS 4
+
+/* face-mass operand layouts (bit flags) */
+#define FE_FM_J_EF   0  /* J[E][nf]      (test_loopy_utils.py:41)            */
+#define FE_FM_J_FE   1  /* J[nf][E]      (tuning/impls/ifj_fe_fej_to_ei.py)  */
+#define FE_FM_R_FIJ  0  /* R[nf][Np][Nfp]                                    */
+#define FE_FM_R_IFJ  2  /* L[Np][nf][Nfp]                                    */
+
+/* ABI version: major*1000 + minor. */
+int fe_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* fe_last_error(void);
+
+/* Number of visible HIP devices (<0: error code). */
+int fe_device_count(void);
+
+/* Device name + the peaks the roofline model uses (GFLOP/s fp64, GB/s HBM).
+ * Replaces cq.device.name + data/device_info.py:5-26. */
+int fe_device_info(int dev, char* name, size_t name_len,
+                   double* peak_f64_gflops, double* peak_gbps);
+
+/* grad:  out[x,e,i] = sum_{r,j} J[x,r,e] * D[r,i,j] * u[e,j]
+ * 'xre,rij,ej->xei' (test/test_codegen.py:96-113); ndim = 3.
+ *   J   [3][3][E]   D [3][Np][Np]   u [E][Np]   out [3][E][Np]              */
+int fe_grad3d_f64(const double* J, const double* D, const double* u,
+                  double* out, int64_t E, int32_t Np, int32_t variant,
+                  void* stream);
+
+/* div:   out[e,i] = sum_{x,r,j} J[x,r,e] * D[r,i,j] * u[x,e,j]
+ * 'xre,rij,xej->ei' (tuning/impls/xre_rij_xej_to_ei.py:26-60).
+ *   J [3][3][E]   D [3][Np][Np]   u [3][E][Np]   out [E][Np]                */
+int fe_div3d_f64(const double* J, const double* D, const double* u,
+                 double* out, int64_t E, int32_t Np, int32_t variant,
+                 void* stream);
+
+/* fused grad + div sharing J and D (BASELINE config 3):
+ *   grad_out[3][E][Np] from u_grad[E][Np];  div_out[E][Np] from v_div[3][E][Np] */
+int fe_graddiv3d_f64(const double* J, const double* D,
+                     const double* u_grad, const double* v_div,
+                     double* grad_out, double* div_out,
+                     int64_t E, int32_t Np, int32_t variant, void* stream);
+
+/* face-mass (lift), b fields sharing J and R:
+ *   out_k[e,i] = sum_{f,j} J[e,f] * R[f,i,j] * v_k[f,e,j],  k = 0..b-1
+ * 'ef,fij,fej->ei' x b (test/test_loopy_utils.py:34-48) or, with layout flags,
+ * 'ifj,fe,fej->ei' (tuning/impls/ifj_fe_fej_to_ei.py:46-60).
+ *   v, out: HOST arrays of b device pointers; v_k [nf][E][Nfp]; out_k [E][Np] */
+int fe_facemass_f64(const double* J, const double* R,
+                    const double* const* v, double* const* out,
+                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                    int32_t layout_flags, int32_t variant, void* stream);
+
+/* Algorithmic flops per element for a family (numerator of GFLOP/s; same
+ * counter as measure.py:278-331 on the opt_einsum-optimal schedule):
+ * grad/div 2*3*Np*Np + 2*9*Np; face-mass b*(nf*Nfp + 2*Np*nf*Nfp). */
+int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf,
+                             int32_t Nfp, int32_t b);
+
+/* Argument pack for fe_time_launches (one struct for every family; unused
+ * fields are ignored). */
+typedef struct fe_argpack {
+    const double* J;
+    const double* D;          /* D (grad/div) or R/L (face-mass)              */
+    const double* u;          /* grad: u[E][Np]; div: u[3][E][Np]             */
+    const double* v_div;      /* graddiv only                                 */
+    double* out;              /* grad / div output; graddiv: grad_out         */
+    double* out2;             /* graddiv: div_out                             */
+    const double* const* v;   /* face-mass inputs  (host array of b ptrs)     */
+    double* const* outs;      /* face-mass outputs (host array of b ptrs)     */
+    int64_t E;
+    int32_t Np, nf, Nfp, b, layout_flags, variant;
+} fe_argpack;
+
+/* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed
+ * by HIP events recorded on that same stream; blocks until the last one is
+ * done and returns the elapsed milliseconds of the whole batch in *ms_out.
+ * Mirrors the 5-launch batches of measure.py:260-273 (evt.wait() fences). */
+int fe_time_launches(int32_t family, const fe_argpack* args, int32_t n_launches,
+                     void* stream, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEINSUM_HIP_H */

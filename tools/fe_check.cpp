@@ -1,0 +1,184 @@
+// fe_check.cpp -- standalone driver for libfeinsum_hip.so: correctness against a
+// host loop nest and device timing, without Python.  Used for quick GPU
+// iterations and as the program under rocprofv3 (fast start-up).
+//
+//   fe_check <family:grad|div|facemass|graddiv> <E> [variant=0] [launches=20] [check=1]
+//
+// Build: hipcc -O2 tools/fe_check.cpp -Lfeinsum_amd -lfeinsum_hip -Wl,-rpath,'$ORIGIN/../feinsum_amd' -o build/fe_check
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../include/feinsum_hip.h"
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                \
+            exit(2);                                                               \
+        }                                                                          \
+    } while (0)
+#define FE(x)                                                                      \
+    do {                                                                           \
+        int r_ = (x);                                                              \
+        if (r_ != 0) {                                                             \
+            fprintf(stderr, "%s -> %d: %s\n", #x, r_, fe_last_error());            \
+            exit(3);                                                               \
+        }                                                                          \
+    } while (0)
+
+static std::vector<double> rnd(size_t n, uint64_t seed) {
+    std::mt19937_64 g(seed);
+    std::uniform_real_distribution<double> d(0.0, 1.0);
+    std::vector<double> v(n);
+    for (auto& x : v) x = d(g);
+    return v;
+}
+static double* to_dev(const std::vector<double>& h) {
+    double* d;
+    CK(hipMalloc(&d, std::max<size_t>(h.size(), 1) * 8));
+    CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: fe_check family E [variant] [launches] [check]\n");
+        return 1;
+    }
+    const std::string fam = argv[1];
+    const int64_t E = atoll(argv[2]);
+    const int variant = argc > 3 ? atoi(argv[3]) : 0;
+    const int launches = argc > 4 ? atoi(argv[4]) : 20;
+    const int check = argc > 5 ? atoi(argv[5]) : 1;
+    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+
+    char name[256];
+    double pf, pb;
+    FE(fe_device_info(0, name, sizeof name, &pf, &pb));
+    printf("device: %s  peak_f64=%.0f GFLOP/s  peak_bw=%.0f GB/s\n", name, pf, pb);
+
+    const int64_t nchk = std::min<int64_t>(E, 4096);  // elements checked on host: first+last
+    double maxrel = 0.0;
+    float ms = 0.f;
+    double flops = 0, bytes = 0;
+
+    if (fam == "grad" || fam == "div" || fam == "graddiv") {
+        auto hJ = rnd(9 * E, 1), hD = rnd(3 * Np * Np, 2);
+        auto hu = rnd(E * Np, 3), hv = rnd(3 * E * Np, 4);
+        double *J = to_dev(hJ), *D = to_dev(hD), *u = to_dev(hu), *v = to_dev(hv);
+        double *og, *od;
+        CK(hipMalloc(&og, std::max<int64_t>(3 * E * Np, 1) * 8));
+        CK(hipMalloc(&od, std::max<int64_t>(E * Np, 1) * 8));
+        CK(hipMemset(og, 0xff, 3 * E * Np * 8));
+        CK(hipMemset(od, 0xff, E * Np * 8));
+        fe_argpack a;
+        memset(&a, 0, sizeof a);
+        a.J = J; a.D = D; a.E = E; a.Np = Np; a.variant = variant;
+        int family;
+        if (fam == "grad") { family = FE_FAMILY_GRAD; a.u = u; a.out = og; }
+        else if (fam == "div") { family = FE_FAMILY_DIV; a.u = v; a.out = od; }
+        else { family = FE_FAMILY_GRADDIV; a.u = u; a.v_div = v; a.out = og; a.out2 = od; }
+        flops = (double)fe_flops_per_element(family, Np, 0, 0, 0) * E;
+        bytes = (family == FE_FAMILY_GRADDIV ? 8.0 * (9 + 35 + 105 + 105 + 35) : 8.0 * 149) * E +
+                8.0 * 3 * Np * Np;
+        float w;
+        FE(fe_time_launches(family, &a, 3, nullptr, &w));  // warm-up
+        FE(fe_time_launches(family, &a, launches, nullptr, &ms));
+        ms /= launches;
+        if (check) {
+            std::vector<double> hg(3 * E * Np), hd(E * Np);
+            CK(hipMemcpy(hg.data(), og, hg.size() * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hd.data(), od, hd.size() * 8, hipMemcpyDeviceToHost));
+            auto chk_elem = [&](int64_t e) {
+                for (int i = 0; i < Np; ++i) {
+                    if (fam != "div") {
+                        long double t[3] = {0, 0, 0};
+                        for (int r = 0; r < 3; ++r)
+                            for (int j = 0; j < Np; ++j)
+                                t[r] += (long double)hD[(r * Np + i) * Np + j] * hu[e * Np + j];
+                        for (int x = 0; x < 3; ++x) {
+                            long double ref = 0;
+                            for (int r = 0; r < 3; ++r) ref += (long double)hJ[(x * 3 + r) * E + e] * t[r];
+                            double got = hg[(x * E + e) * Np + i];
+                            double rel = std::fabs((double)(got - ref)) / std::fabs((double)ref);
+                            if (!(rel <= maxrel)) maxrel = std::isnan(rel) ? 1e300 : std::max(rel, maxrel);
+                        }
+                    }
+                    if (fam != "grad") {
+                        long double ref = 0;
+                        for (int x = 0; x < 3; ++x)
+                            for (int r = 0; r < 3; ++r)
+                                for (int j = 0; j < Np; ++j)
+                                    ref += (long double)hJ[(x * 3 + r) * E + e] *
+                                           hD[(r * Np + i) * Np + j] * hv[(x * E + e) * Np + j];
+                        double got = hd[e * Np + i];
+                        double rel = std::fabs((double)(got - ref)) / std::fabs((double)ref);
+                        if (!(rel <= maxrel)) maxrel = std::isnan(rel) ? 1e300 : std::max(rel, maxrel);
+                    }
+                }
+            };
+            for (int64_t e = 0; e < nchk / 2; ++e) chk_elem(e);
+            for (int64_t e = std::max<int64_t>(nchk / 2, E - (nchk - nchk / 2)); e < E; ++e) chk_elem(e);
+        }
+    } else if (fam == "facemass") {
+        auto hJ = rnd(E * nf, 1), hR = rnd(nf * Np * Nfp, 2);
+        std::vector<std::vector<double>> hv(b);
+        std::vector<const double*> dv(b);
+        std::vector<double*> dout(b);
+        for (int k = 0; k < b; ++k) {
+            hv[k] = rnd(nf * E * Nfp, 10 + k);
+            dv[k] = to_dev(hv[k]);
+            CK(hipMalloc(&dout[k], std::max<int64_t>(E * Np, 1) * 8));
+            CK(hipMemset(dout[k], 0xff, E * Np * 8));
+        }
+        double *J = to_dev(hJ), *R = to_dev(hR);
+        fe_argpack a;
+        memset(&a, 0, sizeof a);
+        a.J = J; a.D = R; a.v = dv.data(); a.outs = dout.data();
+        a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b; a.variant = variant;
+        flops = (double)fe_flops_per_element(FE_FAMILY_FACEMASS, Np, nf, Nfp, b) * E;
+        bytes = 8.0 * (nf + b * nf * Nfp + b * Np) * E + 8.0 * nf * Np * Nfp;
+        float w;
+        FE(fe_time_launches(FE_FAMILY_FACEMASS, &a, 3, nullptr, &w));
+        FE(fe_time_launches(FE_FAMILY_FACEMASS, &a, launches, nullptr, &ms));
+        ms /= launches;
+        if (check) {
+            for (int k = 0; k < b; ++k) {
+                std::vector<double> ho(E * Np);
+                CK(hipMemcpy(ho.data(), dout[k], ho.size() * 8, hipMemcpyDeviceToHost));
+                auto chk_elem = [&](int64_t e) {
+                    for (int i = 0; i < Np; ++i) {
+                        long double ref = 0;
+                        for (int f = 0; f < nf; ++f)
+                            for (int j = 0; j < Nfp; ++j)
+                                ref += (long double)hJ[e * nf + f] * hR[(f * Np + i) * Nfp + j] *
+                                       hv[k][(f * E + e) * Nfp + j];
+                        double rel = std::fabs((double)(ho[e * Np + i] - ref)) / std::fabs((double)ref);
+                        if (!(rel <= maxrel)) maxrel = std::isnan(rel) ? 1e300 : std::max(rel, maxrel);
+                    }
+                };
+                for (int64_t e = 0; e < nchk / 2; ++e) chk_elem(e);
+                for (int64_t e = std::max<int64_t>(nchk / 2, E - (nchk - nchk / 2)); e < E; ++e) chk_elem(e);
+            }
+        }
+    } else {
+        fprintf(stderr, "unknown family %s\n", fam.c_str());
+        return 1;
+    }
+    const double gflops = flops / (ms * 1e-3) * 1e-9, gbs = bytes / (ms * 1e-3) * 1e-9;
+    printf("%s E=%lld variant=%d: %.4f ms/launch  %.1f GFLOP/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)"
+           "  max_rel_err=%.3e %s\n",
+           fam.c_str(), (long long)E, variant, ms, gflops, gbs, gbs / 80.0, maxrel,
+           check ? (maxrel <= 1e-12 ? "PASS" : "FAIL") : "(unchecked)");
+    return (check && !(maxrel <= 1e-12)) ? 4 : 0;
+}
