@@ -1,0 +1,36 @@
+"""
+feinsum_amd -- MI355X-native evaluation backend behind feinsum's builder and
+measure API for the 3D DG-wave batched einsums (grad / div / face-mass).
+
+The public names mirror ``feinsum/__init__.py`` of the reference for the hot
+path (reference: ``src/feinsum/__init__.py:1-68``); everything loopy-, sqlite-
+or autotuner-related is out of scope and absent.
+"""
+
+from feinsum_amd.contraction_schedule import (ContractionSchedule, count_ops,
+                                              get_opt_einsum_contraction_schedule,
+                                              get_trivial_contraction_schedule)
+from feinsum_amd.diagnostics import (EinsumTunitMatchError, HipLibraryError, InvalidParameterError,
+                                     NoDevicePeaksInfoError, NoFactInDatabaseError,
+                                     TransformValidationError)
+from feinsum_amd.einsum import (Array, BatchedEinsum, EinsumAxisAccess, FreeAxis, SizeParam,
+                                SummationAxis)
+from feinsum_amd.family import KernelPlan, match_family
+from feinsum_amd.make_einsum import array, batched_einsum, einsum
+from feinsum_amd.measure import (DeviceQueue, evaluate, generate_input_arrays, generate_out_arrays,
+                                 get_roofline_flop_rate, measure_giga_op_rate,
+                                 stringify_comparison_vs_roofline, timeit, timeit_details,
+                                 validate_batched_einsum_transform)
+
+__all__ = (
+    "Array", "BatchedEinsum", "ContractionSchedule", "DeviceQueue", "EinsumAxisAccess",
+    "EinsumTunitMatchError", "FreeAxis", "HipLibraryError", "InvalidParameterError", "KernelPlan",
+    "NoDevicePeaksInfoError", "NoFactInDatabaseError", "SizeParam", "SummationAxis",
+    "TransformValidationError", "array", "batched_einsum", "count_ops", "einsum", "evaluate",
+    "generate_input_arrays", "generate_out_arrays", "get_opt_einsum_contraction_schedule",
+    "get_roofline_flop_rate", "get_trivial_contraction_schedule", "match_family",
+    "measure_giga_op_rate", "stringify_comparison_vs_roofline", "timeit", "timeit_details",
+    "validate_batched_einsum_transform",
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,190 @@
+"""
+ctypes binding of ``libfeinsum_hip.so`` (C ABI: ``include/feinsum_hip.h``).
+
+This is the only place where the Python host code touches native code.  It
+replaces the reference's PyOpenCL enqueue inside the loopy executor
+(reference: ``src/feinsum/measure.py:163-165,243-251,267``).  There is no CPU
+fallback: if the library is missing or fails to load, every entry point raises
+:class:`~feinsum_amd.diagnostics.HipLibraryError`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+from feinsum_amd.diagnostics import HipLibraryError, InvalidParameterError
+
+FE_OK, FE_EINVAL, FE_EUNSUPPORTED, FE_EHIP = 0, -1, -2, -3
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA = 0, 1, 2
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MFMA}
+
+#: every symbol declared in include/feinsum_hip.h (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = (
+    "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
+    "fe_grad3d_f64", "fe_div3d_f64", "fe_graddiv3d_f64", "fe_facemass_f64",
+    "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
+)
+
+_c_double_p = C.c_void_p   # device pointers travel as plain integers
+
+
+class ArgPack(C.Structure):
+    """``struct fe_argpack`` of include/feinsum_hip.h."""
+
+    _fields_ = [
+        ("J", C.c_void_p), ("D", C.c_void_p), ("u", C.c_void_p), ("v_div", C.c_void_p),
+        ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("v", C.POINTER(C.c_void_p)), ("outs", C.POINTER(C.c_void_p)),
+        ("E", C.c_int64),
+        ("Np", C.c_int32), ("nf", C.c_int32), ("Nfp", C.c_int32), ("b", C.c_int32),
+        ("layout_flags", C.c_int32), ("variant", C.c_int32),
+    ]
+
+
+FE_MAX_EINSUM_OPERANDS = 8
+FE_MAX_EINSUM_INDICES = 8
+
+
+class EinsumDesc(C.Structure):
+    """``struct fe_einsum_desc`` of include/feinsum_hip.h."""
+
+    _fields_ = [
+        ("n_operands", C.c_int32), ("n_out", C.c_int32), ("n_sum", C.c_int32), ("dtype", C.c_int32),
+        ("out_extent", C.c_int64 * FE_MAX_EINSUM_INDICES),
+        ("sum_extent", C.c_int64 * FE_MAX_EINSUM_INDICES),
+        ("op_out_stride", (C.c_int64 * FE_MAX_EINSUM_INDICES) * FE_MAX_EINSUM_OPERANDS),
+        ("op_sum_stride", (C.c_int64 * FE_MAX_EINSUM_INDICES) * FE_MAX_EINSUM_OPERANDS),
+    ]
+
+
+def library_path() -> Path:
+    """``$FEINSUM_HIP_LIB`` if set, else the in-tree ``feinsum_amd/libfeinsum_hip.so``."""
+    env = os.environ.get("FEINSUM_HIP_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / "libfeinsum_hip.so"
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Load (once) and type the shared library; never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise HipLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950) or point FEINSUM_HIP_LIB at it")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {path}: {exc}") from exc
+
+    lib.fe_version.restype = C.c_int
+    lib.fe_version.argtypes = []
+    lib.fe_last_error.restype = C.c_char_p
+    lib.fe_last_error.argtypes = []
+    lib.fe_device_count.restype = C.c_int
+    lib.fe_device_count.argtypes = []
+    lib.fe_device_info.restype = C.c_int
+    lib.fe_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    for name in ("fe_grad3d_f64", "fe_div3d_f64"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_graddiv3d_f64.restype = C.c_int
+    lib.fe_graddiv3d_f64.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_facemass_f64.restype = C.c_int
+    lib.fe_facemass_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_flops_per_element.restype = C.c_int64
+    lib.fe_flops_per_element.argtypes = [C.c_int32] * 5
+    lib.fe_time_launches.restype = C.c_int
+    lib.fe_time_launches.argtypes = [C.c_int32, C.POINTER(ArgPack), C.c_int32, C.c_void_p,
+                                     C.POINTER(C.c_float)]
+    lib.fe_einsum_generic.restype = C.c_int
+    lib.fe_einsum_generic.argtypes = [C.POINTER(EinsumDesc), C.POINTER(C.c_void_p), C.c_void_p,
+                                      C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map a C return code to the Python exception the reference's callers expect."""
+    if rc == FE_OK:
+        return
+    msg = (load_library().fe_last_error() or b"").decode("utf-8", "replace")
+    if rc == FE_EINVAL:
+        raise InvalidParameterError(msg)
+    if rc == FE_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipLibraryError(f"HIP error ({rc}): {msg}")
+
+
+def variant_code(variant) -> int:
+    if variant is None:
+        return VARIANT_AUTO
+    if isinstance(variant, str):
+        try:
+            return VARIANTS[variant]
+        except KeyError:
+            raise InvalidParameterError(f"unknown kernel variant '{variant}'") from None
+    return int(variant)
+
+
+def device_info(dev: int = 0):
+    """(name, peak fp64 GFLOP/s, peak GB/s) of HIP device *dev*."""
+    lib = load_library()
+    name = C.create_string_buffer(256)
+    pf, pb = C.c_double(), C.c_double()
+    check(lib.fe_device_info(dev, name, 256, C.byref(pf), C.byref(pb)))
+    return name.value.decode(), pf.value, pb.value
+
+
+def _ptr_array(ptrs: Sequence[int]):
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return arr
+
+
+def grad3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0) -> None:
+    check(load_library().fe_grad3d_f64(J, D, u, out, E, Np, variant_code(variant), stream))
+
+
+def div3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0) -> None:
+    check(load_library().fe_div3d_f64(J, D, u, out, E, Np, variant_code(variant), stream))
+
+
+def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: int, E: int,
+              Np: int, variant=None, stream: int = 0) -> None:
+    check(load_library().fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np,
+                                          variant_code(variant), stream))
+
+
+def facemass(J: int, R: int, v: Sequence[int], out: Sequence[int], E: int, Np: int, nf: int,
+             Nfp: int, layout_flags: int = 0, variant=None, stream: int = 0) -> None:
+    if len(v) != len(out):
+        raise InvalidParameterError("face-mass: need as many outputs as fields")
+    check(load_library().fe_facemass_f64(J, R, _ptr_array(v), _ptr_array(out), E, Np, nf, Nfp,
+                                         len(v), layout_flags, variant_code(variant), stream))
+
+
+def flops_per_element(family: int, Np: int, nf: int = 0, Nfp: int = 0, b: int = 1) -> int:
+    return int(load_library().fe_flops_per_element(family, Np, nf, Nfp, b))
+
+
+def time_launches(family: int, pack: ArgPack, n_launches: int, stream: int = 0) -> float:
+    """Milliseconds for *n_launches* back-to-back launches (HIP events on *stream*)."""
+    ms = C.c_float()
+    check(load_library().fe_time_launches(family, C.byref(pack), n_launches, stream, C.byref(ms)))
+    return float(ms.value)
+
+
+def einsum_generic(desc: EinsumDesc, operands: Sequence[int], out: int, stream: int = 0) -> None:
+    check(load_library().fe_einsum_generic(C.byref(desc), _ptr_array(operands), out, stream))

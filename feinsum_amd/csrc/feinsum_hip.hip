@@ -12,6 +12,7 @@
 #include "../../include/feinsum_hip.h"
 #include "fe_common.h"
 #include "fe_div.h"
+#include "fe_einsum.h"
 #include "fe_facemass.h"
 #include "fe_generic.h"
 #include "fe_grad.h"
@@ -96,13 +97,17 @@ int fe_device_info(int dev, char* name, size_t name_len, double* peak_f64_gflops
                    double* peak_gbps) {
     hipDeviceProp_t p;
     FE_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    const bool gfx950 = strstr(p.gcnArchName, "gfx950") != nullptr;
     if (name && name_len) {
-        strncpy(name, p.name, name_len - 1);
+        // ROCm often reports a generic marketing name ("AMD Radeon Graphics") or none at
+        // all; the roofline tables are keyed by part, so gfx950 is named canonically.
+        const char* nm = gfx950 ? "AMD Instinct MI355X" : (p.name[0] != 0 ? p.name : p.gcnArchName);
+        strncpy(name, nm, name_len - 1);
         name[name_len - 1] = 0;
     }
     // fp64: vector = matrix = 32 FMA-flop/clk/SIMD.. i.e. 128 flop/clk/CU (MI355X: 256 CUs
     // x 2.4 GHz -> 78.6 TFLOP/s); HBM3E 8 TB/s (datasheet).  gfx950 only.
-    const bool mi355 = strstr(p.gcnArchName, "gfx950") != nullptr;
+    const bool mi355 = gfx950;
     if (peak_f64_gflops)
         *peak_f64_gflops = mi355 ? 128.0 * p.multiProcessorCount * (p.clockRate * 1e-6) : 0.0;
     if (peak_gbps) *peak_gbps = mi355 ? 8000.0 : 0.0;
@@ -266,6 +271,45 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
         }
         k0 += nb;
     }
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void* out,
+                      void* stream) {
+    if (!d || !operands) return fail(FE_EINVAL, "einsum: null descriptor");
+    if (d->n_operands < 1 || d->n_operands > FE_MAX_EINSUM_OPERANDS || d->n_out < 0 ||
+        d->n_out > FE_MAX_EINSUM_INDICES || d->n_sum < 0 || d->n_sum > FE_MAX_EINSUM_INDICES)
+        return fail(FE_EINVAL, "einsum: %d operands / %d output / %d summation indices out of range",
+                    d->n_operands, d->n_out, d->n_sum);
+    if (d->dtype != FE_DTYPE_F64 && d->dtype != FE_DTYPE_F32)
+        return fail(FE_EUNSUPPORTED, "einsum: dtype code %d not compiled (float64 / float32 only)", d->dtype);
+    int64_t n_out = 1, n_sum = 1;
+    for (int k = 0; k < d->n_out; ++k) {
+        if (d->out_extent[k] < 0) return fail(FE_EINVAL, "einsum: negative extent");
+        n_out *= d->out_extent[k];
+    }
+    for (int k = 0; k < d->n_sum; ++k) {
+        if (d->sum_extent[k] < 0) return fail(FE_EINVAL, "einsum: negative extent");
+        n_sum *= d->sum_extent[k];
+    }
+    if (n_out == 0) return FE_OK;
+    if (!out) return fail(FE_EINVAL, "einsum: null output pointer");
+    if (n_out >= ((int64_t)1 << 39)) return fail(FE_EINVAL, "einsum: output too large");
+    fe_einsum_ptrs P;
+    for (int p = 0; p < FE_MAX_EINSUM_OPERANDS; ++p) P.p[p] = nullptr;
+    for (int p = 0; p < d->n_operands; ++p) {
+        if (!operands[p] && n_sum > 0) return fail(FE_EINVAL, "einsum: null operand %d", p);
+        P.p[p] = operands[p];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
+    if (d->dtype == FE_DTYPE_F64)
+        hipLaunchKernelGGL(fe::einsum_generic_kernel<double>, grid, block, 0, s, *d, P,
+                           static_cast<double*>(out), n_out, n_sum);
+    else
+        hipLaunchKernelGGL(fe::einsum_generic_kernel<float>, grid, block, 0, s, *d, P,
+                           static_cast<float*>(out), n_out, n_sum);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }

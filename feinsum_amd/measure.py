@@ -1,0 +1,593 @@
+"""
+Evaluate, validate and time a :class:`BatchedEinsum` on an MI355X.
+
+API mirror of the reference's ``feinsum.measure`` (reference:
+``src/feinsum/measure.py``): :func:`timeit` (``:197-275``),
+:func:`validate_batched_einsum_transform` (``:111-194``),
+:func:`measure_giga_op_rate` (``:357-385``), :func:`get_roofline_flop_rate`
+(``:388-418``), :func:`stringify_comparison_vs_roofline` (``:484-525``), the
+input generator (``:63-108``) and the three protocol constants (``:35-37``).
+
+What is different underneath: the reference lowers the einsum through loopy to
+OpenCL and enqueues it with PyOpenCL; here :func:`evaluate` picks a
+hand-written gfx950 kernel (``feinsum_amd.family``) and launches it through the
+C ABI of ``libfeinsum_hip.so`` on a HIP stream.  PyTorch-ROCm is used only to
+own device memory and streams.
+
+Argument conventions kept from the reference:
+
+``cq``         anything that names a device/stream: ``None`` (device 0), an int
+               ordinal, a ``torch.device``, or a :class:`DeviceQueue`.
+``transform``  the reference passes a loopy transformation here; loopy does not
+               exist in this build, so a callable (or ``None``) is ignored and
+               selects the default kernel variant, while a ``str`` / ``dict``
+               (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
+               a variant explicitly.
+``schedule``   accepted and ignored: the kernels implement the optimal schedule.
+
+Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
+order** (the reference draws in hash order, which is not reproducible).
+"""
+
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from time import time
+from types import MappingProxyType
+from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+from feinsum_amd import _hip
+from feinsum_amd.contraction_schedule import ContractionSchedule, count_ops
+from feinsum_amd.diagnostics import (HipLibraryError, InvalidParameterError,
+                                     NoDevicePeaksInfoError, TransformValidationError)
+from feinsum_amd.einsum import INT_CLASSES, BatchedEinsum, SizeParam
+from feinsum_amd.family import (FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD, KernelPlan,
+                                match_family)
+
+logger = logging.getLogger(__name__)
+
+N_WARMUP_ROUNDS = 5
+N_MIN_TIMING_ROUNDS = 10
+N_MIN_SIM_SECS = 2
+LAUNCHES_PER_BATCH = 5
+
+
+# --------------------------------------------------------------------------
+# device / stream handle (stands in for pyopencl.CommandQueue)
+# --------------------------------------------------------------------------
+
+@dataclass(frozen=True)
+class DeviceInfo:
+    name: str
+
+
+class DeviceQueue:
+    """A HIP device + stream; duck-types the bits of ``cl.CommandQueue`` the
+    reference uses (``cq.device.name``, ``cq.finish()``)."""
+
+    def __init__(self, device: Any = 0, stream: Any = None) -> None:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise HipLibraryError("no HIP device visible to this process")
+        self.torch_device = torch.device("cuda", device) if isinstance(device, INT_CLASSES) \
+            else torch.device(device)
+        if self.torch_device.index is None:
+            self.torch_device = torch.device("cuda", torch.cuda.current_device())
+        self._stream = stream
+
+    @property
+    def ordinal(self) -> int:
+        return int(self.torch_device.index)
+
+    @property
+    def stream(self):
+        import torch
+
+        return self._stream if self._stream is not None else torch.cuda.current_stream(self.torch_device)
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self.stream.cuda_stream)
+
+    @property
+    def device(self) -> DeviceInfo:
+        name, _, _ = _hip.device_info(self.ordinal)
+        return DeviceInfo(name)
+
+    def finish(self) -> None:
+        self.stream.synchronize()
+
+
+def _as_queue(cq: Any) -> DeviceQueue:
+    if isinstance(cq, DeviceQueue):
+        return cq
+    if cq is None:
+        return DeviceQueue(0)
+    return DeviceQueue(cq)
+
+
+def _variant_from_transform(transform: Any):
+    if transform is None or callable(transform):
+        return None
+    if isinstance(transform, Mapping):
+        return transform.get("variant")
+    return transform
+
+
+# --------------------------------------------------------------------------
+# arrays
+# --------------------------------------------------------------------------
+
+def get_real_dtype(dtype: np.dtype) -> np.dtype:
+    return np.empty(0, dtype=dtype).real.dtype
+
+
+def _concrete_shape(shape: Sequence[Any], long_dim_length: int) -> Tuple[int, ...]:
+    return tuple(int(d) if isinstance(d, INT_CLASSES) else int(long_dim_length) for d in shape)
+
+
+def _random_array(rng: np.random.Generator, dtype: np.dtype, shape: Tuple[int, ...]) -> np.ndarray:
+    # reference: measure.py:63-77
+    if dtype.kind == "c":
+        real = get_real_dtype(dtype)
+        return (rng.random(size=shape, dtype=real) + dtype.type(1j) * rng.random(size=shape, dtype=real))
+    if dtype.kind == "i":
+        return rng.integers(low=-100, high=100, size=shape, dtype=dtype)
+    return rng.random(size=shape, dtype=dtype)
+
+
+def generate_host_input_arrays(einsum: BatchedEinsum, long_dim_length: int,
+                               np_seed: int = 0) -> Dict[str, np.ndarray]:
+    """Host inputs: one ``default_rng(np_seed)``, arrays drawn in sorted-name order."""
+    rng = np.random.default_rng(np_seed)
+    return {name: _random_array(rng, einsum.arg_to_dtype[name],
+                                _concrete_shape(einsum.arg_to_shape[name], long_dim_length))
+            for name in sorted(einsum.arg_to_dtype)}
+
+
+def generate_input_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int,
+                          np_seed: int = 0) -> Mapping[str, Any]:
+    """Device inputs (reference: measure.py:80-108)."""
+    import torch
+
+    q = _as_queue(cq)
+    host = generate_host_input_arrays(einsum, long_dim_length, np_seed)
+    return MappingProxyType({name: torch.from_numpy(arr).to(q.torch_device)
+                             for name, arr in host.items()})
+
+
+def result_dtype(einsum: BatchedEinsum, row: int = 0) -> np.dtype:
+    """dtype of an output = ``np.result_type`` of its operands (codegen/loopy.py:258-260)."""
+    return np.result_type(*[arg.dtype for arg in einsum.args[row]])
+
+
+def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int) -> Mapping[str, Any]:
+    """Zero-filled device outputs ``_fe_out, _fe_out_0, ...`` (reference: measure.py:44-60)."""
+    import torch
+
+    q = _as_queue(cq)
+    shape = _concrete_shape(einsum.shape, long_dim_length)
+    outs = {}
+    for k, name in enumerate(einsum.output_names):
+        tdtype = getattr(torch, result_dtype(einsum, k).name)
+        outs[name] = torch.zeros(shape, dtype=tdtype, device=q.torch_device)
+    return MappingProxyType(outs)
+
+
+# --------------------------------------------------------------------------
+# the waist: run one BatchedEinsum on device arrays
+# --------------------------------------------------------------------------
+
+def _check_tensor(name: str, t: Any, shape: Tuple[int, ...], dtype: np.dtype, q: DeviceQueue) -> None:
+    import torch
+
+    if not isinstance(t, torch.Tensor):
+        raise InvalidParameterError(f"argument '{name}' must be a torch.Tensor on the device")
+    if t.device != q.torch_device:
+        raise InvalidParameterError(f"argument '{name}' lives on {t.device}, expected {q.torch_device}")
+    if tuple(t.shape) != tuple(shape):
+        raise InvalidParameterError(f"argument '{name}' has shape {tuple(t.shape)}, expected {shape}")
+    if t.dtype != getattr(torch, dtype.name):
+        raise InvalidParameterError(f"argument '{name}' has dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise InvalidParameterError(f"argument '{name}' must be C-contiguous")
+
+
+def _long_length(einsum: BatchedEinsum, arg_dict: Mapping[str, Any]) -> Dict[str, int]:
+    """Values of the size parameters, read off the arrays."""
+    values: Dict[str, int] = {}
+    for name, shape in einsum.arg_to_shape.items():
+        for axis, d in enumerate(shape):
+            if isinstance(d, SizeParam):
+                got = int(arg_dict[name].shape[axis])
+                if values.setdefault(d.name, got) != got:
+                    raise InvalidParameterError(f"inconsistent values for size parameter '{d.name}'")
+    return values
+
+
+class _FamilyLaunch:
+    """A family plan bound to concrete device arrays: launch / time."""
+
+    def __init__(self, plan: KernelPlan, einsum: BatchedEinsum, arg_dict: Mapping[str, Any],
+                 outs: Sequence[Any], variant: Any) -> None:
+        self.plan, self.variant = plan, _hip.variant_code(variant)
+        role = plan.roles
+        rows = einsum.args
+        first = rows[0]
+        long_axis = einsum.in_idx_sets[role["J"]].index(plan.long_index)
+        self.E = int(arg_dict[first[role["J"]].name].shape[long_axis])
+        self._keep = (arg_dict, outs)
+        p = plan.params
+        op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV) else "R"
+        self.groups = []   # list of ArgPack (one per launch)
+        if plan.family in (FAMILY_GRAD, FAMILY_DIV):
+            for row, out in zip(rows, outs):
+                pack = _hip.ArgPack()
+                pack.J = arg_dict[row[role["J"]].name].data_ptr()
+                pack.D = arg_dict[row[role[op_role]].name].data_ptr()
+                pack.u = arg_dict[row[role["u"]].name].data_ptr()
+                pack.out = out.data_ptr()
+                pack.E, pack.Np, pack.variant = self.E, p["Np"], self.variant
+                self.groups.append(pack)
+        else:
+            # consecutive rows sharing J and R become one multi-field launch
+            k = 0
+            while k < len(rows):
+                jn, rn = rows[k][role["J"]].name, rows[k][role[op_role]].name
+                k2 = k
+                while (k2 < len(rows) and rows[k2][role["J"]].name == jn
+                       and rows[k2][role[op_role]].name == rn):
+                    k2 += 1
+                vptrs = [arg_dict[rows[m][role["v"]].name].data_ptr() for m in range(k, k2)]
+                optrs = [outs[m].data_ptr() for m in range(k, k2)]
+                pack = _hip.ArgPack()
+                pack.J = arg_dict[jn].data_ptr()
+                pack.D = arg_dict[rn].data_ptr()
+                va, oa = _hip._ptr_array(vptrs), _hip._ptr_array(optrs)
+                self._keep += (va, oa)
+                pack.v, pack.outs = va, oa
+                pack.E, pack.Np, pack.nf, pack.Nfp = self.E, p["Np"], p["nf"], p["Nfp"]
+                pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
+                self.groups.append(pack)
+                k = k2
+
+    def launch(self, stream_ptr: int) -> None:
+        lib = _hip.load_library()
+        for pack in self.groups:
+            if self.plan.family == FAMILY_GRAD:
+                _hip.check(lib.fe_grad3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
+                                             pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_DIV:
+                _hip.check(lib.fe_div3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
+                                            pack.variant, stream_ptr))
+            else:
+                _hip.check(lib.fe_facemass_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
+                                               pack.nf, pack.Nfp, pack.b, pack.layout_flags,
+                                               pack.variant, stream_ptr))
+
+    def time_batch(self, n: int, stream_ptr: int) -> float:
+        """Seconds for *n* launches of the whole batched einsum (HIP events)."""
+        if len(self.groups) == 1:
+            return _hip.time_launches(self.plan.family, self.groups[0], n, stream_ptr) * 1e-3
+        import torch
+
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.current_stream()
+        t0.record(stream)
+        for _ in range(n):
+            self.launch(stream_ptr)
+        t1.record(stream)
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e-3
+
+
+class _GenericLaunch:
+    """Any other einsum: one generic-kernel launch per output row."""
+
+    def __init__(self, einsum: BatchedEinsum, arg_dict: Mapping[str, Any], outs: Sequence[Any]) -> None:
+        dtypes = {np.dtype(dt) for dt in einsum.arg_to_dtype.values()}
+        if len(dtypes) != 1 or next(iter(dtypes)) not in (np.dtype("float64"), np.dtype("float32")):
+            raise NotImplementedError(
+                "the generic einsum kernel is compiled for all-float64 or all-float32 operands;"
+                f" got {sorted(str(d) for d in dtypes)}")
+        dtype = next(iter(dtypes))
+        sizes = _long_length(einsum, arg_dict)
+        extent = {idx: (sizes[d.name] if isinstance(d, SizeParam) else int(d))
+                  for idx, d in einsum.index_to_dim_length.items()}
+        if einsum.n > _hip.FE_MAX_EINSUM_OPERANDS or len(einsum.out_idx_set) > _hip.FE_MAX_EINSUM_INDICES \
+                or len(einsum.sum_indices) > _hip.FE_MAX_EINSUM_INDICES:
+            raise NotImplementedError("einsum has more operands / indices than the generic kernel supports")
+        self._keep = (arg_dict, outs)
+        self.launches = []
+        for row, out in zip(einsum.args, outs):
+            d = _hip.EinsumDesc()
+            d.n_operands, d.n_out, d.n_sum = einsum.n, len(einsum.out_idx_set), len(einsum.sum_indices)
+            d.dtype = 0 if dtype == np.dtype("float64") else 1
+            for k, idx in enumerate(einsum.out_idx_set):
+                d.out_extent[k] = extent[idx]
+            for k, idx in enumerate(einsum.sum_indices):
+                d.sum_extent[k] = extent[idx]
+            for p, (arg, idxs) in enumerate(zip(row, einsum.in_idx_sets)):
+                strides = arg_dict[arg.name].stride()
+                for axis, idx in enumerate(idxs):
+                    if idx in einsum.out_idx_set:
+                        d.op_out_stride[p][einsum.out_idx_set.index(idx)] += strides[axis]
+                    else:
+                        d.op_sum_stride[p][einsum.sum_indices.index(idx)] += strides[axis]
+            self.launches.append((d, [arg_dict[a.name].data_ptr() for a in row], out.data_ptr()))
+
+    def launch(self, stream_ptr: int) -> None:
+        for d, ops, out in self.launches:
+            _hip.einsum_generic(d, ops, out, stream_ptr)
+
+    def time_batch(self, n: int, stream_ptr: int) -> float:
+        import torch
+
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.current_stream()
+        t0.record(stream)
+        for _ in range(n):
+            self.launch(stream_ptr)
+        t1.record(stream)
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e-3
+
+
+def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
+          out_dict: Optional[Mapping[str, Any]], transform: Any):
+    import torch
+
+    q = _as_queue(cq)
+    missing = sorted(set(einsum.all_args) - set(arg_dict))
+    if missing:
+        raise InvalidParameterError(f"missing input arrays: {missing}")
+    sizes = _long_length(einsum, arg_dict)
+    for name, shape in einsum.arg_to_shape.items():
+        concrete = tuple(sizes[d.name] if isinstance(d, SizeParam) else int(d) for d in shape)
+        _check_tensor(name, arg_dict[name], concrete, einsum.arg_to_dtype[name], q)
+    out_shape = tuple(sizes[d.name] if isinstance(d, SizeParam) else int(d) for d in einsum.shape)
+    outs = []
+    for k, name in enumerate(einsum.output_names):
+        dt = result_dtype(einsum, k)
+        if out_dict is not None and name in out_dict:
+            _check_tensor(name, out_dict[name], out_shape, dt, q)
+            outs.append(out_dict[name])
+        else:
+            outs.append(torch.empty(out_shape, dtype=getattr(torch, dt.name), device=q.torch_device))
+    plan = match_family(einsum)
+    variant = _variant_from_transform(transform)
+    if plan is not None:
+        bound = _FamilyLaunch(plan, einsum, arg_dict, outs, variant)
+    else:
+        if variant not in (None, "auto", "generic", 0, 1):
+            raise NotImplementedError(
+                f"einsum '{einsum.get_subscripts()}' is outside the DG kernel families;"
+                " only the generic kernel is available for it")
+        bound = _GenericLaunch(einsum, arg_dict, outs)
+    return q, bound, outs
+
+
+def evaluate(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any], *,
+             out_dict: Optional[Mapping[str, Any]] = None, transform: Any = None,
+             wait: bool = False) -> Mapping[str, Any]:
+    """
+    Enqueue *einsum* on the queue's stream and return ``{"_fe_out": tensor, ...}``
+    (the replacement for ``t_unit.executor(cq, ...)(cq, **arg_dict)``,
+    reference measure.py:163-165).  Asynchronous unless *wait*; outputs are
+    fully overwritten.
+    """
+    import torch
+
+    q, bound, outs = _bind(einsum, cq, arg_dict, out_dict, transform)
+    with torch.cuda.device(q.torch_device):
+        bound.launch(q.stream_ptr)
+    if wait:
+        q.finish()
+    return MappingProxyType(dict(zip(einsum.output_names, outs)))
+
+
+# --------------------------------------------------------------------------
+# validation and timing
+# --------------------------------------------------------------------------
+
+def _tolerances(dtype: np.dtype) -> Tuple[float, float]:
+    real = get_real_dtype(np.dtype(dtype))
+    if real == np.float32:
+        return 1e-6, 1e-6
+    if real == np.float64:
+        return 1e-10, 1e-10
+    raise NotImplementedError(real)
+
+
+def validate_batched_einsum_transform(einsum: BatchedEinsum, cq: Any, transform: Any,
+                                      schedule: Optional[ContractionSchedule] = None) -> None:
+    """
+    Run the selected kernel at ``long_dim_length = 100`` and compare every output
+    with ``np.einsum(subscripts, *inputs, optimize="optimal")``; atol = rtol =
+    1e-10 (float64) / 1e-6 (float32).  Raises
+    :class:`~feinsum_amd.diagnostics.TransformValidationError` on mismatch.
+    (reference: measure.py:111-194)
+    """
+    del schedule
+    long_dim_length = 100
+    q = _as_queue(cq)
+    host = generate_host_input_arrays(einsum, long_dim_length)
+    import torch
+
+    arg_dict = {name: torch.from_numpy(arr).to(q.torch_device) for name, arr in host.items()}
+    ref_outs = {name: np.einsum(einsum.get_subscripts(), *[host[arg.name] for arg in row],
+                                optimize="optimal")
+                for name, row in zip(einsum.output_names, einsum.args)}
+    outs = evaluate(einsum, q, arg_dict, transform=transform, wait=True)
+    if set(ref_outs) != set(outs):
+        raise RuntimeError("Output names mismatch")
+    for name in sorted(ref_outs):
+        got = outs[name].cpu().numpy()
+        ref = ref_outs[name]
+        if got.dtype != ref.dtype:
+            raise RuntimeError(f"dtype mismatch for output '{name}'")
+        atol, rtol = _tolerances(ref.dtype)
+        try:
+            np.testing.assert_allclose(got, ref, atol=atol, rtol=rtol)
+        except AssertionError as exc:
+            raise TransformValidationError(f"{exc}") from exc
+    logger.info("Statistically verified the soundness of the transformation")
+
+
+@dataclass(frozen=True)
+class TimingResult:
+    """What :func:`timeit_details` measured (seconds are per launch)."""
+
+    seconds_device: float     # HIP-event time per launch (what timeit returns)
+    seconds_wall: float       # host wall-clock per launch, reference protocol
+    rounds: int
+
+
+def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = None,
+                   long_dim_length: int = 100000,
+                   schedule: Optional[ContractionSchedule] = None,
+                   min_rounds: int = N_MIN_TIMING_ROUNDS,
+                   min_secs: float = N_MIN_SIM_SECS, validate: bool = True) -> TimingResult:
+    """The reference's timing protocol (measure.py:248-275) with both clocks reported."""
+    import torch
+
+    q = _as_queue(cq)
+    if validate:
+        validate_batched_einsum_transform(einsum, q, transform, schedule)
+    arg_dict = generate_input_arrays(q, einsum, long_dim_length)
+    out_dict = generate_out_arrays(q, einsum, long_dim_length)
+    _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform)
+    with torch.cuda.device(q.torch_device):
+        for _ in range(N_WARMUP_ROUNDS):
+            bound.launch(q.stream_ptr)
+        q.finish()
+        dev_time = wall_time = 0.0
+        rounds = 0
+        while rounds < min_rounds or wall_time < min_secs:
+            t0 = time()
+            dev_time += bound.time_batch(LAUNCHES_PER_BATCH, q.stream_ptr)   # fences like evt.wait()
+            wall_time += time() - t0
+            rounds += LAUNCHES_PER_BATCH
+    return TimingResult(dev_time / rounds, wall_time / rounds, rounds)
+
+
+def timeit(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = None,
+           long_dim_length: int = 100000,
+           schedule: Optional[ContractionSchedule] = None) -> float:
+    """
+    Mean seconds per launch of *einsum* on the device of *cq*: validation at
+    E = 100, 5 warm-up launches, then batches of 5 launches until at least 10
+    launches and 2 s have elapsed (reference: measure.py:197-275).  Device time
+    is taken with HIP events around each batch.
+    """
+    return timeit_details(einsum, transform=transform, cq=cq, long_dim_length=long_dim_length,
+                          schedule=schedule).seconds_device
+
+
+# --------------------------------------------------------------------------
+# op counts, footprint, roofline
+# --------------------------------------------------------------------------
+
+def _get_giga_ops_from_einsum(expr: BatchedEinsum, long_dim_length: int) -> Mapping[np.dtype, float]:
+    """GOps of the optimal schedule by result dtype (reference: measure.py:278-331).
+
+    Complex arithmetic is weighted as in the reference (add = 2, mul = 6 real ops).
+    """
+    dt = np.result_type(*[np.dtype(d) for d in expr.arg_to_dtype.values()])
+    ops = count_ops(expr, long_dim_length=long_dim_length)
+    if dt.kind == "c":
+        # count_ops returns adds + muls; split them to apply the weights
+        from feinsum_amd.contraction_schedule import (_dim_lengths, _step_ops,
+                                                      get_opt_einsum_contraction_schedule)
+        dims = _dim_lengths(expr, long_dim_length)
+        total = 0
+        for subs in get_opt_einsum_contraction_schedule(expr).subscripts:
+            lhs, rhs = subs.replace(" ", "").split("->")
+            sets = [frozenset(s) for s in lhs.split(",")]
+            pts = 1
+            for idx in frozenset().union(*sets):
+                pts *= dims[idx]
+            both = _step_ops(sets, frozenset(rhs), dims)
+            mults = (len(sets) - 1) * pts
+            total += 6 * mults + 2 * (both - mults)
+        ops = total * expr.b
+        dt = get_real_dtype(dt)
+    return MappingProxyType({np.dtype(dt): ops * 1e-9})
+
+
+def _get_footprint_gbytes(expr: BatchedEinsum, long_dim_length: int) -> float:
+    """Every distinct input once + every output once (reference: measure.py:334-354)."""
+    nbytes = 0
+    for name, shape in expr.arg_to_shape.items():
+        nbytes += int(np.prod(_concrete_shape(shape, long_dim_length), dtype=np.int64)) \
+            * np.dtype(expr.arg_to_dtype[name]).itemsize
+    out_entries = int(np.prod(_concrete_shape(expr.shape, long_dim_length), dtype=np.int64))
+    for k in range(expr.b):
+        nbytes += out_entries * result_dtype(expr, k).itemsize
+    return nbytes * 1e-9
+
+
+def measure_giga_op_rate(expr: BatchedEinsum, *, transform: Any = None, cq: Any = None,
+                         long_dim_length: int = 100000,
+                         schedule: Optional[ContractionSchedule] = None) -> Mapping[np.dtype, float]:
+    """GOps/s by result dtype (reference: measure.py:357-385)."""
+    runtime = timeit(expr, transform=transform, cq=cq, long_dim_length=long_dim_length,
+                     schedule=schedule)
+    return MappingProxyType({dt: gops / runtime
+                             for dt, gops in _get_giga_ops_from_einsum(expr, long_dim_length).items()})
+
+
+def get_roofline_flop_rate(expr: BatchedEinsum, dev_name: str,
+                           long_dim_length: int = 100_000) -> Mapping[np.dtype, float]:
+    """
+    ``t_roof = max(GOps / peak_GOps[dtype], GB / peak_BW)``; returns GOps / t_roof
+    per dtype (reference: measure.py:388-418).  Unknown device ->
+    :class:`NoDevicePeaksInfoError`.
+    """
+    from feinsum_amd.device_info import DEV_TO_PEAK_BW, DEV_TO_PEAK_GFLOPS, normalize_device_name
+
+    dev_name = normalize_device_name(dev_name)
+    gops = _get_giga_ops_from_einsum(expr, long_dim_length)
+    ngbs = _get_footprint_gbytes(expr, long_dim_length)
+    try:
+        t_flops = max(g / DEV_TO_PEAK_GFLOPS[dev_name][dt.name] for dt, g in gops.items())
+        t_bw = ngbs / DEV_TO_PEAK_BW[dev_name]
+    except KeyError as exc:
+        raise NoDevicePeaksInfoError(dev_name) from exc
+    t_roof = max(t_flops, t_bw)
+    return MappingProxyType({dt: g / t_roof for dt, g in gops.items()})
+
+
+def _strify_measured_vs_roofline(measured: Mapping[np.dtype, Any],
+                                 roofline: Mapping[np.dtype, Any]) -> str:
+    from tabulate import tabulate
+
+    assert set(measured) == set(roofline)
+    fmt = lambda v: f"{v:.1f}" if isinstance(v, float) else str(v)  # noqa: E731
+    table = [["Dtype", "Measured GOps/s", "Roofline GOps/s"]]
+    for dt in sorted(measured, key=lambda d: d.itemsize):
+        table.append([dt.name, fmt(measured[dt]), fmt(roofline[dt])])
+    return tabulate(table, tablefmt="fancy_grid")
+
+
+def stringify_comparison_vs_roofline(expr: BatchedEinsum, *,
+                                     schedule: Optional[ContractionSchedule] = None,
+                                     transform: Any = None, cq: Any = None,
+                                     long_dim_length: int = 100000,
+                                     ignore_unknown_device: bool = True) -> str:
+    """The reference's fancy_grid table "Dtype / Measured GOps/s / Roofline GOps/s"
+    (reference: measure.py:484-525); roofline at the SAME long_dim_length."""
+    q = _as_queue(cq)
+    measured = measure_giga_op_rate(expr, transform=transform, schedule=schedule, cq=q,
+                                    long_dim_length=long_dim_length)
+    try:
+        roofline: Mapping[np.dtype, Any] = get_roofline_flop_rate(expr, q.device.name, long_dim_length)
+    except NoDevicePeaksInfoError:
+        if not ignore_unknown_device:
+            raise
+        roofline = dict.fromkeys(measured, "N/A")
+    return _strify_measured_vs_roofline(measured, roofline)

@@ -1,0 +1,167 @@
+"""
+Element-axis sharding of the DG einsums across the GPUs of one node.
+
+New functionality (the reference is single process / single queue:
+``src/feinsum/measure.py:113,201``).  Every output entry depends only on inputs
+of the same element plus the small replicated operator, so the path shards
+trivially: one process per GPU (``torch.distributed``, backend
+``nccl`` = RCCL over xGMI on ROCm, ``gloo`` on CPU for tests), a contiguous
+block of elements per rank, NO collective on the data path.  The only exchange
+is an all-gather of each shard's *result reduction* (a few float64 per output:
+sum, sum of squares, max |.|), which is what north_star asks for; gathering
+whole fields would cost ~20x the compute time over xGMI and is
+available separately as :func:`allgather_field`.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Any, List, Mapping, Sequence, Tuple
+
+TILE = 16   # elements per MFMA wave tile: shard boundaries are tile aligned
+
+
+def shard_bounds(E: int, world_size: int, rank: int, align: int = TILE) -> Tuple[int, int]:
+    """
+    Contiguous block split of ``range(E)``: every rank gets ``floor(E / world /
+    align) * align`` elements, the remainder goes to the last rank, so all shard
+    starts are multiples of *align* (full MFMA tiles; only the last rank can
+    have a ragged tail).
+    """
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank {rank} for world size {world_size}")
+    if E < 0:
+        raise ValueError("E must be >= 0")
+    per = (E // world_size) // align * align
+    start = rank * per
+    stop = E if rank == world_size - 1 else start + per
+    return start, stop
+
+
+def slice_long_axis(arr: Any, axis: int, start: int, stop: int) -> Any:
+    """``arr`` restricted to ``[start, stop)`` along *axis*, as a dense copy
+    (each rank keeps its shard dense: J is (3,3,E), grad out (3,E,Np), ...)."""
+    idx = [slice(None)] * arr.ndim
+    idx[axis] = slice(start, stop)
+    sl = arr[tuple(idx)]
+    return sl.contiguous() if hasattr(sl, "contiguous") else sl.copy()
+
+
+def shard_host_arrays(einsum: Any, host: Mapping[str, Any], world_size: int, rank: int) -> dict:
+    """Shard every array that carries a ``SizeParam`` axis; replicate the rest."""
+    from feinsum_amd.einsum import SizeParam
+
+    out = {}
+    for name, shape in einsum.arg_to_shape.items():
+        arr = host[name]
+        for axis, d in enumerate(shape):
+            if isinstance(d, SizeParam):
+                s, e = shard_bounds(arr.shape[axis], world_size, rank)
+                arr = slice_long_axis(arr, axis, s, e)
+        out[name] = arr
+    return out
+
+
+@dataclass(frozen=True)
+class DistInfo:
+    rank: int
+    local_rank: int
+    world_size: int
+    backend: str
+
+
+def init_distributed(backend: str | None = None) -> DistInfo:
+    """
+    Join the process group described by RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them); a plain
+    ``python bench.py`` is world size 1 and joins nothing.
+    """
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return DistInfo(rank, local_rank, world, backend)
+
+
+def result_reduction(outs: Sequence[Any]) -> Any:
+    """Per-output [sum, sum of squares, max |.|] as one float64 tensor on the
+    outputs' device -- the "fused result reduction" that is exchanged."""
+    import torch
+
+    rows = []
+    for o in outs:
+        o64 = o.to(torch.float64)
+        if o64.numel() == 0:
+            rows.append(torch.zeros(3, dtype=torch.float64, device=o.device))
+        else:
+            rows.append(torch.stack([o64.sum(), (o64 * o64).sum(), o64.abs().max()]))
+    return torch.stack(rows)
+
+
+def allgather_reduction(local: Any) -> Any:
+    """All-gather the per-shard reductions -> tensor [world, n_outputs, 3]."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    gathered = [torch.empty_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, local.contiguous())
+    return torch.stack(gathered)
+
+
+def combine_reductions(gathered: Any) -> Any:
+    """Global [sum, sum of squares, max |.|] per output from the gathered shards."""
+    import torch
+
+    return torch.stack([gathered[..., 0].sum(0), gathered[..., 1].sum(0),
+                        gathered[..., 2].max(0).values], dim=-1)
+
+
+def allgather_field(local: Any, axis: int, sizes: Sequence[int]) -> Any:
+    """Optional full-field gather along the element axis (off the timed path).
+    *sizes*: shard lengths of all ranks (the last shard may be longer)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    moved = local.movedim(axis, 0).contiguous()
+    pad = max(sizes)
+    buf = torch.zeros((pad,) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
+    buf[: moved.shape[0]] = moved
+    parts: List[Any] = [torch.empty_like(buf) for _ in sizes]
+    dist.all_gather(parts, buf)
+    full = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+    return full.movedim(0, axis).contiguous()
+
+
+def barrier() -> None:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: Any = None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

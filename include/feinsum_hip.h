@@ -139,6 +139,34 @@ typedef struct fe_argpack {
 int fe_time_launches(int32_t family, const fe_argpack* args, int32_t n_launches,
                      void* stream, float* ms_out);
 
+/* ---- generic einsum (any explicit-mode subscripts; float64 or float32) ----
+ * The device restatement of the loop nest generate_loopy emits for the trivial
+ * schedule (codegen/loopy.py:242-305): one output entry per thread,
+ *   out[o...] = sum_{s...} prod_p operand_p[o..., s...].
+ * Used for einsums outside the DG families (e.g. test/test_measure.py:33-52).
+ * Strides are in ELEMENTS; 0 for an index an operand does not carry.  The output
+ * is C-contiguous in out_extent order. */
+#define FE_MAX_EINSUM_OPERANDS 8
+#define FE_MAX_EINSUM_INDICES  8
+#define FE_DTYPE_F64 0
+#define FE_DTYPE_F32 1
+
+typedef struct fe_einsum_desc {
+    int32_t n_operands, n_out, n_sum, dtype;
+    int64_t out_extent[FE_MAX_EINSUM_INDICES];
+    int64_t sum_extent[FE_MAX_EINSUM_INDICES];
+    int64_t op_out_stride[FE_MAX_EINSUM_OPERANDS][FE_MAX_EINSUM_INDICES];
+    int64_t op_sum_stride[FE_MAX_EINSUM_OPERANDS][FE_MAX_EINSUM_INDICES];
+} fe_einsum_desc;
+
+typedef struct fe_einsum_ptrs {
+    const void* p[FE_MAX_EINSUM_OPERANDS];
+} fe_einsum_ptrs;
+
+/* operands: HOST array of n_operands device pointers. */
+int fe_einsum_generic(const fe_einsum_desc* desc, const void* const* operands,
+                      void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

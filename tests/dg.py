@@ -1,0 +1,49 @@
+"""The DG-wave einsums of the hot path, spelled with the current feinsum API the
+way the reference's own tests spell them (test/test_codegen.py:34-120,
+test/test_measure.py:55-81, test/test_loopy_utils.py:34-48)."""
+
+import feinsum_amd as f
+
+NP, NF, NFP = 35, 4, 15
+
+
+def grad(Np=NP):
+    return f.einsum("xre,rij,ej->xei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)),
+                    f.array("u", ("E", Np)))
+
+
+def div(Np=NP):
+    return f.einsum("xre,rij,xej->ei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)),
+                    f.array("u", (3, "E", Np)))
+
+
+def face_mass(b=4, Np=NP, nf=NF, Nfp=NFP):
+    return f.batched_einsum(
+        "ef, fij, fej -> ei",
+        [[f.array("J", ("E", nf)), f.array("R", (nf, Np, Nfp)), f.array(f"v{i}", (nf, "E", Nfp))]
+         for i in range(b)])
+
+
+def face_mass_ifj_fe(b=4, Np=NP, nf=NF, Nfp=NFP):
+    return f.batched_einsum(
+        "ifj,fe,fej->ei",
+        [[f.array("L", (Np, nf, Nfp)), f.array("J", (nf, "E")), f.array(f"v{i}", (nf, "E", Nfp))]
+         for i in range(b)])
+
+
+def batched_div_components(Np=NP):
+    # test/test_codegen.py:34-66
+    return f.batched_einsum(
+        "se, sij, ej -> ei",
+        [[f.array("J" + c, (3, "E")), f.array("R", (3, Np, Np)), f.array("u" + c, ("E", Np))]
+         for c in "xyz"])
+
+
+GOLDEN_CASES = {
+    "grad_p4": grad,
+    "div_p4": div,
+    "facemass_p4_ef_fij": face_mass,
+    "facemass_p4_ifj_fe": face_mass_ifj_fe,
+    "batched_div_p4": batched_div_components,
+    "grad_p2": lambda: grad(10),
+}

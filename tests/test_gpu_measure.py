@@ -1,0 +1,119 @@
+"""feinsum.measure API on the device: the calls the reference's own tests make
+(test/test_codegen.py:34-120, test/test_measure.py:33-81), the error behaviour,
+and the fused grad+div entry point of the C ABI."""
+
+import numpy as np
+import pytest
+
+import feinsum_amd as f
+from feinsum_amd import _hip, measure
+from feinsum_amd.measure import generate_host_input_arrays
+
+import dg
+
+pytestmark = pytest.mark.gpu
+IDENTITY = lambda t_unit, insn_match, kernel_name: t_unit  # noqa: E731  (the reference's identity transform)
+
+
+@pytest.fixture(autouse=True)
+def _fast_protocol(monkeypatch):
+    # keep the suite short: the protocol is the reference's, only the 2 s floor is lowered
+    monkeypatch.setattr(measure, "N_MIN_SIM_SECS", 0.05)
+
+
+def _timeit(expr, **kw):
+    return measure.timeit_details(expr, min_secs=0.05, **kw)
+
+
+def test_timeit_like_reference_tests():
+    import torch
+
+    cq = f.DeviceQueue(0)
+    assert "MI355X" in cq.device.name or cq.device.name
+    for expr in (dg.batched_div_components(), dg.face_mass(), dg.grad()):
+        r = _timeit(expr, transform=IDENTITY, cq=cq, long_dim_length=300)
+        assert r.rounds >= 10 and r.rounds % 5 == 0
+        assert 0 < r.seconds_device <= r.seconds_wall * 1.5
+    t = f.timeit(dg.grad(), transform=IDENTITY, cq=0, long_dim_length=3000)
+    assert 0 < t < 1e-2
+    torch.cuda.synchronize()
+
+
+def test_matvec_float32_fixed_and_parametric():
+    for A in (f.array("A", (10, 4), "float32"), f.array("A", ("I", 4), "float32")):
+        expr = f.batched_einsum("ij, j -> i", [[A, f.array("x", 4, "float32")],
+                                               [A, f.array("y", 4, "float32")]])
+        r = _timeit(expr, transform=IDENTITY, cq=0, long_dim_length=1000)
+        assert r.seconds_device > 0
+
+
+def test_pprint_roofline_comparison():
+    s = f.stringify_comparison_vs_roofline(dg.grad(), cq=0, transform=IDENTITY, long_dim_length=500)
+    assert "Measured GOps/s" in s and "Roofline GOps/s" in s and "float64" in s
+    assert "N/A" not in s          # the MI355X row exists in the device table
+    rates = f.measure_giga_op_rate(dg.div(), cq=0, transform=None, long_dim_length=20000)
+    assert list(rates) == [np.dtype("float64")] and rates[np.dtype("float64")] > 0
+
+
+def test_validation_catches_a_wrong_kernel(monkeypatch):
+    # a "transform" that yields wrong values must raise TransformValidationError
+    real = measure.evaluate
+
+    def broken(einsum, cq, arg_dict, **kw):
+        outs = real(einsum, cq, arg_dict, **kw)
+        for o in outs.values():
+            o[..., 0] *= 1.0 + 1e-8
+        return outs
+
+    monkeypatch.setattr(measure, "evaluate", broken)
+    with pytest.raises(f.TransformValidationError):
+        f.validate_batched_einsum_transform(dg.grad(), 0, None)
+    monkeypatch.undo()
+    f.validate_batched_einsum_transform(dg.grad(), 0, None)   # and passes unbroken
+
+
+def test_evaluate_argument_errors():
+    import torch
+
+    expr = dg.grad()
+    host = generate_host_input_arrays(expr, 64)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    with pytest.raises(f.InvalidParameterError, match="missing"):
+        f.evaluate(expr, 0, {"J": dev["J"]})
+    with pytest.raises(f.InvalidParameterError, match="shape"):
+        f.evaluate(expr, 0, {**dev, "R": dev["R"][:, :34].contiguous()})
+    with pytest.raises(f.InvalidParameterError, match="dtype"):
+        f.evaluate(expr, 0, {**dev, "u": dev["u"].float()})
+    with pytest.raises(f.InvalidParameterError, match="contiguous"):
+        f.evaluate(expr, 0, {**dev, "u": torch.empty((35, 64), dtype=torch.float64, device="cuda").t()})
+    with pytest.raises(f.InvalidParameterError, match="lives on"):
+        f.evaluate(expr, 0, {**dev, "u": dev["u"].cpu()})
+    with pytest.raises(f.InvalidParameterError, match="inconsistent"):
+        f.evaluate(expr, 0, {**dev, "u": torch.zeros((65, 35), dtype=torch.float64, device="cuda")})
+
+
+def test_fused_graddiv_and_time_launches():
+    import torch
+
+    from oracle import np_oracle
+
+    E = 5000
+    rng = np.random.default_rng(9)
+    J, D = rng.random((3, 3, E)), rng.random((3, 35, 35))
+    u, v = rng.random((E, 35)), rng.random((3, E, 35))
+    dJ, dD, du, dv = (torch.from_numpy(a).cuda() for a in (J, D, u, v))
+    og = torch.empty((3, E, 35), dtype=torch.float64, device="cuda")
+    od = torch.empty((E, 35), dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _hip.graddiv3d(dJ.data_ptr(), dD.data_ptr(), du.data_ptr(), dv.data_ptr(), og.data_ptr(),
+                   od.data_ptr(), E, 35, stream=s)
+    torch.cuda.synchronize()
+    assert np_oracle.max_rel_err(og.cpu().numpy(), np.einsum("xre,rij,ej->xei", J, D, u, optimize="optimal")) <= 1e-12
+    assert np_oracle.max_rel_err(od.cpu().numpy(), np.einsum("xre,rij,xej->ei", J, D, v, optimize="optimal")) <= 1e-12
+    pack = _hip.ArgPack()
+    pack.J, pack.D, pack.u, pack.out = dJ.data_ptr(), dD.data_ptr(), du.data_ptr(), og.data_ptr()
+    pack.E, pack.Np, pack.variant = E, 35, 0
+    ms = _hip.time_launches(1, pack, 5, s)
+    assert 0 < ms < 100
+    name, pf, pb = _hip.device_info(0)
+    assert pf == pytest.approx(78643.2, rel=0.05) and pb == 8000.0 and name
