@@ -38,6 +38,19 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_base) {
         : "v"(g), "s"(lds_base)
         : "memory");
 }
+__device__ __forceinline__ void glds16_nt(const void* g, unsigned lds_base) {   // non-temporal hint
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_base)
+        : "memory");
+}
 __device__ __forceinline__ void glds4(const void* g, unsigned lds_base) {
     unsigned keep;
     lds_base = __builtin_amdgcn_readfirstlane(lds_base);

@@ -5,24 +5,27 @@
 //
 // Schedule = the opt_einsum-optimal one: first the cheap
 // Jacobian contraction  Ju[r,e,j] = sum_x J[x,r,e] u[x,e,j]  (VALU, 3 FMAs per
-// value, produced directly in MFMA B-fragment layout), then the dense one
-//   out[i, e] = sum_{(r,j)} D'[i, (r,j)] * Ju[(r,j), e]
-// on v_mfma_f64_16x16x4_f64 with A = D' (35 x 105 zero padded to 48 x 108)
-// resident in registers (81 doubles / lane) and 3 x 27 = 81 MFMAs per tile of
-// 16 elements per wave.  K is ordered (jq, r) with j = 4 jq + g so that one
-// group of three u values (x = 0..2) feeds three consecutive k-steps.
-// Data movement as in fe_grad.h: LDS-DMA in (3 u planes + J), LDS transpose
-// out, 1-KiB contiguous stores, waves fully independent.  The three u planes
-// (13.4 KB per wave) do not leave LDS room for a second buffer at 8 waves/CU,
-// so the loads of tile t+1 are issued right after tile t's last MFMA (its
-// LDS reads are done by then) and overlap only tile t's epilogue; the other
-// wave of the SIMD covers the rest of the latency.
+// value, produced directly in MFMA B-fragment layout and kept in registers),
+// then the dense one  out[i, e] = sum_{(j,r)} D'[i, (j,r)] * Ju[(j,r), e]  on the
+// matrix cores, A = D' (35 x 105, K padded to 108) resident in registers:
+//   rows  0..31  two 16-row tiles on v_mfma_f64_16x16x4_f64   (2 x 27 MFMAs, 64 cycles each)
+//   rows 32..34  on v_mfma_f64_4x4x4_4b_f64: its four 4x4x4 blocks are four groups of
+//                four elements sharing one (replicated) 4-row slice of D', so the 3
+//                leftover rows cost 27 x 16 cycles instead of a third 16-row tile
+//                (27 x 64).  Its B operand layout (lane = 16 k + column) is the
+//                16x16x4 one, so the same B registers feed both instructions.
+// K is ordered (jq, r) with j = 4 jq + g: one group of three u values (x = 0..2)
+// feeds three consecutive k-steps.
+// Data movement as in fe_grad.h.  The three u planes (13.4 KB per wave) leave
+// no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a
+// tile are computed up front (27 doubles / lane), which frees the u buffer, and
+// the next tile's loads are issued before this tile's MFMAs and stores.
 #pragma once
 #include "fe_grad.h"
 
 namespace fe {
 
-constexpr int kDivRowTiles = 3;   // 35 -> 48 rows
+constexpr int kDivBigTiles = 2;   // rows 0..31
 constexpr int kDivJq = 9;         // 35 -> 36 j's, 4 per k-step
 
 struct DivWaveLds {
@@ -32,8 +35,12 @@ struct DivWaveLds {
 };
 static_assert(sizeof(DivWaveLds) == 19072, "LDS budget");
 constexpr int kDivWavesPerBlock = 4;
-constexpr int kDivLdsBytes = sizeof(DivWaveLds) * kDivWavesPerBlock;  // 76288: 2 blocks / CU
+constexpr int kDivASmallD = 27 * 4 * 4;   // D' rows 32..35 as [k-step][g][row], shared by the block
+constexpr int kDivLdsBytes = sizeof(DivWaveLds) * kDivWavesPerBlock + kDivASmallD * 8;  // 79744: 2 blocks / CU
+constexpr int kDivLoadsPerTile = 20, kDivStoresPerTile = 5;
 
+// kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
+template <int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
     double* __restrict__ out, int64_t E, int64_t nTiles) {
@@ -43,24 +50,33 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     DivWaveLds* L = reinterpret_cast<DivWaveLds*>(smem) + wave;
     const int n = lane & 15, g = lane >> 4;
 
-    // ---- A fragments: lane (g, n) supplies A[row i = 16t + n][k = (jq, r)], j = 4 jq + g
-    double afrag[kDivRowTiles][kDivJq][3];
+    // ---- A fragments.  16x16x4: lane (g, n) supplies A[row 16t + n][k = g];
+    //      4x4x4_4b: lane (g, n) supplies block n/4, row 32 + n%4 (row 35 = zero padding), k = g.
+    //      The 4-row slice is identical for the four blocks, so it lives once in LDS
+    //      (3.4 KB per block, broadcast reads) instead of 54 VGPRs per lane.
+    double abig[kDivBigTiles][kDivJq][3];
 #pragma unroll
-    for (int t = 0; t < kDivRowTiles; ++t) {
-        const int i = 16 * t + n;
+    for (int jq = 0; jq < kDivJq; ++jq) {
+        const int j = 4 * jq + g;
 #pragma unroll
-        for (int jq = 0; jq < kDivJq; ++jq) {
-            const int j = 4 * jq + g;
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-                afrag[t][jq][r] = (i < kNp35 && j < kNp35) ? D[(r * kNp35 + i) * kNp35 + j] : 0.0;
-        }
+            for (int t = 0; t < kDivBigTiles; ++t)
+                abig[t][jq][r] = (j < kNp35) ? D[(r * kNp35 + 16 * t + n) * kNp35 + j] : 0.0;
     }
+    double* asmall = reinterpret_cast<double*>(smem + sizeof(DivWaveLds) * kDivWavesPerBlock);
+    for (int idx = threadIdx.x; idx < kDivASmallD; idx += 256) {
+        const int ks = idx >> 4, gg = (idx >> 2) & 3, i3 = 32 + (idx & 3);
+        const int j = 4 * (ks / 3) + gg, r = ks % 3;
+        asmall[idx] = (j < kNp35 && i3 < kNp35) ? D[(r * kNp35 + i3) * kNp35 + j] : 0.0;
+    }
+    __syncthreads();   // the only block-level barrier: one-time operator staging
+    const double* as_lane = asmall + g * 4 + (n & 3);
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)gridDim.x * kDivWavesPerBlock;
-    // 3 planes x 5 x 16-byte LDS-DMA + 5 x 4-byte LDS-DMA for J
+    // 3 planes x 5 x 16-byte LDS-DMA + 5 x 4-byte LDS-DMA for J = 20 vector-memory ops
     auto issue_loads = [&](int64_t tile) {
         const int64_t e0 = tile * kTE;
         const char* ub = reinterpret_cast<const char*>(u) + e0 * (kNp35 * 8) + lane * 16;
@@ -69,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
             const char* up = ub + (int64_t)x * E * (kNp35 * 8);
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (c < 4 || lane < 24) glds16(up + c * 1024, lds_u + x * kTileB35 + c * 1024);
+                if (c < 4 || lane < 24) glds16_nt(up + c * 1024, lds_u + x * kTileB35 + c * 1024);
         }
         const int w = lane & 31;
         const char* jb = reinterpret_cast<const char*>(J) + e0 * 8 + w * 4;
@@ -81,21 +97,19 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     };
     int64_t tile = (int64_t)blockIdx.x * kDivWavesPerBlock + wave;
     bool first = true;
-    if (tile < nTiles) issue_loads(tile);
+    if (tile < nTiles && !(kDbg & 8)) issue_loads(tile);
     for (; tile < nTiles; tile += stride) {
         const int64_t e0 = tile * kTE;
-        // issue order: L(t) S(t-1) | wait L(t): the previous tile's 5 stores stay in flight
-        if (first) wait_vmcnt<0>();
-        else wait_vmcnt<5>();
+        // issue order: ... L(t) [MFMAs(t-1)] S(t-1) | wait L(t): the previous tile's stores are younger
+        if (first || (kDbg & 10)) wait_vmcnt<0>();
+        else wait_vmcnt<kDivStoresPerTile>();
         first = false;
 
+        // ---- all B fragments: Ju[(jq, r)][e = n], j = 4 jq + g
         double jac[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) jac[k] = L->j[k * kTE + n];   // jac[x*3 + r]
-
-        v4d acc[kDivRowTiles];
-#pragma unroll
-        for (int t = 0; t < kDivRowTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+        double bfrag[kDivJq][3];
 #pragma unroll
         for (int jq = 0; jq < kDivJq; ++jq) {
             const int j = 4 * jq + g;
@@ -105,29 +119,48 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
             double u2 = L->u[2][n * kNp35 + jc];
             if (j >= kNp35) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double b = jac[0 * 3 + r] * u0 + jac[1 * 3 + r] * u1 + jac[2 * 3 + r] * u2;
+            for (int r = 0; r < 3; ++r)
+                bfrag[jq][r] = jac[0 * 3 + r] * u0 + jac[1 * 3 + r] * u1 + jac[2 * 3 + r] * u2;
+        }
+        // the u / J tiles are now in registers: hand the buffers back to the DMA engine
 #pragma unroll
-                for (int t = 0; t < kDivRowTiles; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][jq][r], b, acc[t], 0, 0, 0);
-            }
+        for (int jq = 0; jq < kDivJq; ++jq)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
+        if (tile + stride < nTiles && !(kDbg & 8)) issue_loads(tile + stride);
+
+        // ---- 54 + 27 MFMAs
+        v4d acc[kDivBigTiles];
+        double acc3 = 0.0;
+#pragma unroll
+        for (int t = 0; t < kDivBigTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+        if (kDbg & 1) {
+            double sum = 0.0;
+#pragma unroll
+            for (int jq = 0; jq < kDivJq; ++jq)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) sum += bfrag[jq][r];
+            acc[0] = v4d{sum, sum, sum, sum}; acc[1] = acc[0]; acc3 = sum + abig[0][0][0] + abig[1][8][2];
+        } else {
+#pragma unroll
+            for (int jq = 0; jq < kDivJq; ++jq)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int t = 0; t < kDivBigTiles; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[jq][r], acc[t], 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[(jq * 3 + r) * 16], bfrag[jq][r], acc3, 0, 0, 0);
+                }
         }
 
-        // u / J tiles are fully consumed (every LDS read fed an MFMA that has
-        // issued): hand the buffer back to the DMA engine for the next tile.
-#pragma unroll
-        for (int t = 0; t < kDivRowTiles; ++t) asm volatile("" : "+v"(acc[t]));
-        if (tile + stride < nTiles) issue_loads(tile + stride);
-
-        // ---- transposed store: lane (g, n) holds out[e0 + n][i = 16t + g + 4q]
+        // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e0 + n][16t + g + 4q];
+        //      4x4x4_4b D: lane (g, n) holds out[e0 + n][32 + g] (g == 3 is padding)
         double* ob = L->o;
 #pragma unroll
-        for (int t = 0; t < kDivRowTiles; ++t)
+        for (int t = 0; t < kDivBigTiles; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * t + g + 4 * q;
-                if (i < kNp35) ob[n * kNp35 + i] = acc[t][q];
-            }
+            for (int q = 0; q < 4; ++q) ob[n * kNp35 + 16 * t + g + 4 * q] = acc[t][q];
+        if (g < 3) ob[n * kNp35 + 32 + g] = acc3;
         wave_lds_fence();
         double* op = out + e0 * kNp35;
 #pragma unroll
@@ -135,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
             if (c < 4 || lane < 24) {
                 const int q = c * 64 + lane;
                 const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                *reinterpret_cast<v2d*>(op + 2 * q) = val;
+                if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * q] = val[1]; }
+                else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
             }
         }
         wave_lds_fence();

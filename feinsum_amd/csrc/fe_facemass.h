@@ -7,9 +7,11 @@
 // Schedule = the opt_einsum-optimal one: Jv_k[(f,j), e] = J[e,f] v_k[f,e,j] (one
 // multiply, VALU, produced in MFMA B-fragment layout), then
 //   out_k[i, e] = sum_{(f,j)} R'[i, (f,j)] * Jv_k[(f,j), e]
-// on v_mfma_f64_16x16x4_f64: A = R' (35 x 60, rows padded to 48; K = 60 = 15
-// k-steps exactly) resident in registers (45 doubles / lane), 3 x 15 = 45 MFMAs
-// per (16-element tile, field) "unit" per wave.
+// on the matrix cores, A = R' (35 x 60; K = 60 = 15 k-steps exactly) resident in
+// registers (45 doubles / lane): rows 0..31 as two 16-row tiles on
+// v_mfma_f64_16x16x4_f64 (2 x 15 MFMAs of 64 cycles) and rows 32..34 on
+// v_mfma_f64_4x4x4_4b_f64 (15 x 16 cycles; see fe_div.h) per (16-element tile,
+// field) "unit" per wave.
 // Data movement: a unit's four face slabs (4 x 1920 contiguous bytes) come in
 // by LDS-DMA into a 2-slot ring, two units ahead; J for a tile (512 B) comes with
 // its first unit; results leave through a separate LDS transposition buffer as
@@ -26,7 +28,7 @@ constexpr int kFmNf = 4, kFmNfp = 15;
 constexpr int kFmSlabD = kTE * kFmNfp;            // 240 doubles = 1920 bytes per face
 constexpr int kFmUnitD = kFmNf * kFmSlabD;        // 960 doubles = 7680 bytes
 constexpr int kFmKSteps = 15;                     // K = 60
-constexpr int kFmRowTiles = 3;                    // 35 -> 48
+constexpr int kFmBigTiles = 2;                    // rows 0..31; rows 32..34 on 4x4x4_4b
 
 struct FmWaveLds {
     double v[2][kFmUnitD];     // ring of field slabs: v[slot][f][e][j]
@@ -49,8 +51,8 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 #pragma unroll
     for (int f = 0; f < kFmNf; ++f) {
         const char* vf = vb + (int64_t)f * E * (kFmNfp * 8);
-        glds16(vf, lds_v + f * (kFmSlabD * 8));
-        if (lane < 56) glds16(vf + 1024, lds_v + f * (kFmSlabD * 8) + 1024);
+        glds16_nt(vf, lds_v + f * (kFmSlabD * 8));
+        if (lane < 56) glds16_nt(vf + 1024, lds_v + f * (kFmSlabD * 8) + 1024);
     }
     if (kWithJ) {
         const char* jb = reinterpret_cast<const char*>(J);
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
     // ---- per-lane K decomposition: k = 4 ks + g = 15 f + j
     int voff[kFmKSteps];   // offset of v[f][n][j] inside a unit slab
     int joff[kFmKSteps];   // offset of J[e0+n][f] inside the J tile
-    double afrag[kFmRowTiles][kFmKSteps];
+    double abig[kFmBigTiles][kFmKSteps];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
+    double asmall[kFmKSteps];              // 4x4x4_4b: block n/4, row 32 + n%4 (row 35 = zero), k = g
 #pragma unroll
     for (int ks = 0; ks < kFmKSteps; ++ks) {
         const int k = 4 * ks + g;
@@ -85,11 +88,13 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
         voff[ks] = f * kFmSlabD + n * kFmNfp + j;
         joff[ks] = jfe ? f * kTE + n : n * kFmNf + f;
 #pragma unroll
-        for (int t = 0; t < kFmRowTiles; ++t) {
+        for (int t = 0; t < kFmBigTiles; ++t) {
             const int i = 16 * t + n;
-            const int ridx = rifj ? (i * kFmNf + f) * kFmNfp + j : (f * kNp35 + i) * kFmNfp + j;
-            afrag[t][ks] = (i < kNp35) ? R[ridx] : 0.0;
+            abig[t][ks] = R[rifj ? (i * kFmNf + f) * kFmNfp + j : (f * kNp35 + i) * kFmNfp + j];
         }
+        const int i3 = 32 + (n & 3), i3c = i3 < kNp35 ? i3 : 0;
+        const double a3 = R[rifj ? (i3c * kFmNf + f) * kFmNfp + j : (f * kNp35 + i3c) * kFmNfp + j];
+        asmall[ks] = (i3 < kNp35) ? a3 : 0.0;
     }
 
     const unsigned lds_v0 = lds_addr_uniform(L->v[0]);
@@ -145,25 +150,27 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
                 }
             }
 
-            // ---- 45 MFMAs
-            v4d acc[kFmRowTiles];
+            // ---- 30 + 15 MFMAs
+            v4d acc[kFmBigTiles];
+            double acc3 = 0.0;
 #pragma unroll
-            for (int t = 0; t < kFmRowTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < kFmBigTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ks = 0; ks < kFmKSteps; ++ks)
+            for (int ks = 0; ks < kFmKSteps; ++ks) {
 #pragma unroll
-                for (int t = 0; t < kFmRowTiles; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                for (int t = 0; t < kFmBigTiles; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(asmall[ks], bfrag[ks], acc3, 0, 0, 0);
+            }
 
-            // ---- transposed store: lane (g, n) holds out[e0 + n][i = 16t + g + 4q]
+            // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e0 + n][16t + g + 4q];
+            //      4x4x4_4b D: lane (g, n) holds out[e0 + n][32 + g] (g == 3 is padding)
             double* ob = L->o;
 #pragma unroll
-            for (int t = 0; t < kFmRowTiles; ++t)
+            for (int t = 0; t < kFmBigTiles; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 16 * t + g + 4 * q;
-                    if (i < kNp35) ob[n * kNp35 + i] = acc[t][q];
-                }
+                for (int q = 0; q < 4; ++q) ob[n * kNp35 + 16 * t + g + 4 * q] = acc[t][q];
+            if (g < 3) ob[n * kNp35 + 32 + g] = acc3;
             wave_lds_fence();
             double* op = P.out[k] + tile * (kTE * kNp35);
 #pragma unroll
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
                 if (c < 4 || lane < 24) {
                     const int q = c * 64 + lane;
                     const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                    *reinterpret_cast<v2d*>(op + 2 * q) = val;
+                    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
                 }
             }
             wave_lds_fence();

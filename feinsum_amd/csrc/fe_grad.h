@@ -46,6 +46,7 @@ constexpr int kGradLdsBytes = sizeof(GradWaveLds) * kGradWavesPerBlock;  // 8089
 // LDS-DMA) for one FULL tile (the kernel only ever sees full tiles; the host
 // sends the E % 16 remainder to the generic kernel), so the counted vmcnt in
 // the main loop is always right.
+template <bool kNT = false>
 __device__ __forceinline__ void grad_issue_tile_loads(const double* __restrict__ J,
                                                       const double* __restrict__ u,
                                                       int64_t E, int64_t tile, int lane,
@@ -54,7 +55,10 @@ __device__ __forceinline__ void grad_issue_tile_loads(const double* __restrict__
     const char* ub = reinterpret_cast<const char*>(u) + e0 * (kNp35 * 8) + lane * 16;
 #pragma unroll
     for (int c = 0; c < 5; ++c)
-        if (c < 4 || lane < 24) glds16(ub + c * 1024, lds_u + c * 1024);
+        if (c < 4 || lane < 24) {
+            if (kNT) glds16_nt(ub + c * 1024, lds_u + c * 1024);
+            else glds16(ub + c * 1024, lds_u + c * 1024);
+        }
     const int w = lane & 31;               // dword inside a 128-byte row
     const char* jb = reinterpret_cast<const char*>(J) + e0 * 8 + w * 4;
 #pragma unroll
@@ -66,6 +70,11 @@ __device__ __forceinline__ void grad_issue_tile_loads(const double* __restrict__
 constexpr int kGradLoadsPerTile = 10;
 constexpr int kGradStoresPerTile = 15;   // 3 planes x 5 x 16-byte stores
 
+// kDbg: experiment flags, 0 in the product build (tools/fe_check.cpp "ab" mode uses the others
+// through build/libfeinsum_hip_exp.so): 1 skip MFMAs, 2 skip stores, 4 plain (temporal) stores,
+// 8 skip loads, 16 plain (temporal) loads.  Product: non-temporal on both sides -- every byte is
+// touched once (A/B on MI355X: -2.5 % kernel time, -7 % for the data-movement skeleton).
+template <int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
     double* __restrict__ out, int64_t E, int64_t nTiles) {
@@ -96,21 +105,24 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
     int64_t tile = (int64_t)blockIdx.x * kGradWavesPerBlock + wave;
     int buf = 0;
     bool first = true;
-    if (tile < nTiles)
-        grad_issue_tile_loads(J, u, E, tile, lane, lds_addr_uniform(L->u[0]), lds_addr_uniform(L->j[0]));
+    if (tile < nTiles && !(kDbg & 8))
+        grad_issue_tile_loads<(kDbg & 16) == 0>(J, u, E, tile, lane, lds_addr_uniform(L->u[0]), lds_addr_uniform(L->j[0]));
 
     for (; tile < nTiles; tile += stride, buf ^= 1) {
         // Vector-memory ops in issue order: L(t) S(t-1) L(t+1) | wait L(t).  The
         // 15 stores of the previous tile and the 10 loads of the next one are
         // younger than this tile's loads and stay in flight.
         const int64_t nxt = tile + stride;
-        if (nxt < nTiles) {
-            grad_issue_tile_loads(J, u, E, nxt, lane, lds_addr_uniform(L->u[buf ^ 1]),
+        if (kDbg & 8) {
+            wait_vmcnt<0>();
+        } else if (nxt < nTiles) {
+            grad_issue_tile_loads<(kDbg & 16) == 0>(J, u, E, nxt, lane, lds_addr_uniform(L->u[buf ^ 1]),
                                   lds_addr_uniform(L->j[buf ^ 1]));
-            if (first) wait_vmcnt<kGradLoadsPerTile>();
+            if (kDbg & 2) wait_vmcnt<kGradLoadsPerTile>();
+            else if (first) wait_vmcnt<kGradLoadsPerTile>();
             else wait_vmcnt<kGradLoadsPerTile + kGradStoresPerTile>();
         } else {
-            if (first) wait_vmcnt<0>();
+            if (first || (kDbg & 2)) wait_vmcnt<0>();
             else wait_vmcnt<kGradStoresPerTile>();
         }
         first = false;
@@ -127,11 +139,17 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
         v4d acc[kGradRowTiles];
 #pragma unroll
         for (int t = 0; t < kGradRowTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < kGradKSteps; ++ks)
+        if (kDbg & 1) {
 #pragma unroll
             for (int t = 0; t < kGradRowTiles; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                acc[t] = v4d{bfrag[t], bfrag[t + 1], bfrag[t + 2], afrag[t][0]};
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < kGradKSteps; ++ks)
+#pragma unroll
+                for (int t = 0; t < kGradRowTiles; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+        }
 
         // ---- stage 2 + transposed store
         const double* jt = L->j[buf];
@@ -160,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
                 if (c < 4 || lane < 24) {
                     const int q = c * 64 + lane;
                     const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                    *reinterpret_cast<v2d*>(op + 2 * q) = val;
+                    if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * q] = val[1]; }   // keep the value live
+                    else if (kDbg & 4) *reinterpret_cast<v2d*>(op + 2 * q) = val;
+                    else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
                 }
             }
             wave_lds_fence();

@@ -75,7 +75,7 @@ unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 25
 // CU (their VGPR / LDS residency), fewer when there is less work.
 unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
     int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
-    const int64_t cap = 2 * (int64_t)device_cu_count();
+    const int64_t cap = (8 / wavesPerBlock) * (int64_t)device_cu_count();   // 8 waves per CU
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
@@ -128,7 +128,11 @@ int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp
 int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
                   int32_t Np, int32_t variant, void* stream) {
     if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+#ifdef FE_EXPERIMENTS
+    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
+#else
     if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+#endif
         return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -139,12 +143,40 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
     if (variant != FE_VARIANT_GENERIC && mfma_ok) {
         const int64_t nTiles = E / fe::kTE;   // full tiles; the remainder goes to the generic kernel
         if (nTiles > 0) {
+            int dbg = 0;
+#ifdef FE_EXPERIMENTS
+            if (variant >= 1000) dbg = (variant - 1000) & 31;   // experiment flags, see fe_grad.h
+#endif
+            const unsigned grid = persistent_grid(nTiles, fe::kGradWavesPerBlock);
             static std::once_flag once;
             static int attr_rc = FE_OK;
-            std::call_once(once, [] { attr_rc = set_max_lds(fe::grad3d_np35_mfma_kernel, fe::kGradLdsBytes); });
+            std::call_once(once, [] {
+                attr_rc = set_max_lds(fe::grad3d_np35_mfma_kernel<0>, fe::kGradLdsBytes);
+#ifdef FE_EXPERIMENTS
+                set_max_lds(fe::grad3d_np35_mfma_kernel<1>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<2>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<4>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<16>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<20>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<21>, fe::kGradLdsBytes);
+#endif
+            });
             if (attr_rc != FE_OK) return attr_rc;
-            hipLaunchKernelGGL(fe::grad3d_np35_mfma_kernel, dim3(persistent_grid(nTiles, fe::kGradWavesPerBlock)),
-                               dim3(256), fe::kGradLdsBytes, s, J, D, u, out, E, nTiles);
+            const dim3 g(grid), b(256);
+#define FE_GRAD_CASE(DBG) \
+    hipLaunchKernelGGL(fe::grad3d_np35_mfma_kernel<DBG>, g, b, fe::kGradLdsBytes, s, J, D, u, out, E, nTiles)
+            switch (dbg) {
+#ifdef FE_EXPERIMENTS
+                case 1: FE_GRAD_CASE(1); break;
+                case 2: FE_GRAD_CASE(2); break;
+                case 4: FE_GRAD_CASE(4); break;
+                case 16: FE_GRAD_CASE(16); break;
+                case 20: FE_GRAD_CASE(20); break;
+                case 21: FE_GRAD_CASE(21); break;
+#endif
+                default: FE_GRAD_CASE(0); break;
+            }
+#undef FE_GRAD_CASE
             e_done = nTiles * fe::kTE;
         }
     }
@@ -158,7 +190,11 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
 int fe_div3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
                  int32_t Np, int32_t variant, void* stream) {
     if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+#ifdef FE_EXPERIMENTS
+    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
+#else
     if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+#endif
         return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -171,10 +207,29 @@ int fe_div3d_f64(const double* J, const double* D, const double* u, double* out,
         if (nTiles > 0) {
             static std::once_flag once;
             static int attr_rc = FE_OK;
-            std::call_once(once, [] { attr_rc = set_max_lds(fe::div3d_np35_mfma_kernel, fe::kDivLdsBytes); });
+            std::call_once(once, [] {
+                attr_rc = set_max_lds(fe::div3d_np35_mfma_kernel<0>, fe::kDivLdsBytes);
+#ifdef FE_EXPERIMENTS
+                set_max_lds(fe::div3d_np35_mfma_kernel<1>, fe::kDivLdsBytes);
+                set_max_lds(fe::div3d_np35_mfma_kernel<2>, fe::kDivLdsBytes);
+                set_max_lds(fe::div3d_np35_mfma_kernel<3>, fe::kDivLdsBytes);
+                set_max_lds(fe::div3d_np35_mfma_kernel<8>, fe::kDivLdsBytes);
+#endif
+            });
             if (attr_rc != FE_OK) return attr_rc;
-            hipLaunchKernelGGL(fe::div3d_np35_mfma_kernel, dim3(persistent_grid(nTiles, fe::kDivWavesPerBlock)),
-                               dim3(256), fe::kDivLdsBytes, s, J, D, u, out, E, nTiles);
+            const dim3 g(persistent_grid(nTiles, fe::kDivWavesPerBlock)), b(256);
+#define FE_DIV_CASE(DBG) \
+    hipLaunchKernelGGL(fe::div3d_np35_mfma_kernel<DBG>, g, b, fe::kDivLdsBytes, s, J, D, u, out, E, nTiles)
+            switch (variant >= 1000 ? (variant - 1000) & 15 : 0) {
+#ifdef FE_EXPERIMENTS
+                case 1: FE_DIV_CASE(1); break;
+                case 2: FE_DIV_CASE(2); break;
+                case 3: FE_DIV_CASE(3); break;
+                case 8: FE_DIV_CASE(8); break;
+#endif
+                default: FE_DIV_CASE(0); break;
+            }
+#undef FE_DIV_CASE
             e_done = nTiles * fe::kTE;
         }
     }

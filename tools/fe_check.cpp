@@ -6,6 +6,7 @@
 //
 // Build: hipcc -O2 tools/fe_check.cpp -Lfeinsum_amd -lfeinsum_hip -Wl,-rpath,'$ORIGIN/../feinsum_amd' -o build/fe_check
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -50,7 +51,107 @@ static double* to_dev(const std::vector<double>& h) {
     return d;
 }
 
+// In-process A/B: interleaved rounds over several variants (methodology rule: compare in ONE
+// process, report median and min).   fe_check ab <grad|div|facemass> E rounds launches v1,v2,...
+static int ab_main(int argc, char** argv) {
+    const std::string fam = argv[2];
+    const int64_t E = atoll(argv[3]);
+    const int rounds = atoi(argv[4]), launches = atoi(argv[5]);
+    std::vector<int> variants;
+    for (char* tok = strtok(argv[6], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
+    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+    fe_argpack a;
+    memset(&a, 0, sizeof a);
+    a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
+    int family;
+    double flops, bytes;
+    std::vector<const double*> dv(b);
+    std::vector<double*> dout(b);
+    if (fam == "grad" || fam == "div") {
+        a.J = to_dev(rnd(9 * E, 1)); a.D = to_dev(rnd(3 * Np * Np, 2));
+        a.u = to_dev(rnd((fam == "grad" ? 1 : 3) * E * Np, 3));
+        double* o; CK(hipMalloc(&o, (fam == "grad" ? 3 : 1) * E * Np * 8)); a.out = o;
+        family = fam == "grad" ? FE_FAMILY_GRAD : FE_FAMILY_DIV;
+        flops = 7980.0 * E; bytes = 1192.0 * E;
+    } else {
+        a.J = to_dev(rnd(E * nf, 1)); a.D = to_dev(rnd(nf * Np * Nfp, 2));
+        for (int k = 0; k < b; ++k) { dv[k] = to_dev(rnd(nf * E * Nfp, 10 + k)); CK(hipMalloc(&dout[k], E * Np * 8)); }
+        a.v = dv.data(); a.outs = dout.data();
+        family = FE_FAMILY_FACEMASS; flops = 17040.0 * E; bytes = 3072.0 * E;
+    }
+    std::vector<std::vector<float>> t(variants.size());
+    float ms;
+    for (size_t v = 0; v < variants.size(); ++v) { a.variant = variants[v]; FE(fe_time_launches(family, &a, 3, nullptr, &ms)); }
+    for (int r = 0; r < rounds; ++r)
+        for (size_t v = 0; v < variants.size(); ++v) {
+            a.variant = variants[v];
+            FE(fe_time_launches(family, &a, launches, nullptr, &ms));
+            t[v].push_back(ms / launches);
+        }
+    for (size_t v = 0; v < variants.size(); ++v) {
+        std::sort(t[v].begin(), t[v].end());
+        const float med = t[v][t[v].size() / 2], mn = t[v].front();
+        printf("%s E=%lld variant %5d: median %.4f ms (%.0f GFLOP/s, %.0f GB/s)  min %.4f ms  max %.4f ms\n", fam.c_str(),
+               (long long)E, variants[v], med, flops / med * 1e-6, bytes / med * 1e-6, mn, t[v].back());
+    }
+    return 0;
+}
+
+// A/B between BUILDS in one process: the same launches through several copies of the library
+// (dlopen), interleaved.   fe_check abl <grad|div|facemass> E rounds launches libA.so libB.so ...
+typedef int (*time_fn)(int32_t, const fe_argpack*, int32_t, void*, float*);
+static int abl_main(int argc, char** argv) {
+    const std::string fam = argv[2];
+    const int64_t E = atoll(argv[3]);
+    const int rounds = atoi(argv[4]), launches = atoi(argv[5]);
+    std::vector<time_fn> fns;
+    std::vector<std::string> names;
+    for (int i = 6; i < argc; ++i) {
+        void* h = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "dlopen %s: %s\n", argv[i], dlerror()); return 2; }
+        fns.push_back((time_fn)dlsym(h, "fe_time_launches"));
+        names.push_back(argv[i]);
+    }
+    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+    fe_argpack a;
+    memset(&a, 0, sizeof a);
+    a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
+    int family;
+    double flops, bytes;
+    std::vector<const double*> dv(b);
+    std::vector<double*> dout(b);
+    if (fam == "grad" || fam == "div") {
+        a.J = to_dev(rnd(9 * E, 1)); a.D = to_dev(rnd(3 * Np * Np, 2));
+        a.u = to_dev(rnd((fam == "grad" ? 1 : 3) * E * Np, 3));
+        double* o; CK(hipMalloc(&o, (fam == "grad" ? 3 : 1) * E * Np * 8)); a.out = o;
+        family = fam == "grad" ? FE_FAMILY_GRAD : FE_FAMILY_DIV;
+        flops = 7980.0 * E; bytes = 1192.0 * E;
+    } else {
+        a.J = to_dev(rnd(E * nf, 1)); a.D = to_dev(rnd(nf * Np * Nfp, 2));
+        for (int k = 0; k < b; ++k) { dv[k] = to_dev(rnd(nf * E * Nfp, 10 + k)); CK(hipMalloc(&dout[k], E * Np * 8)); }
+        a.v = dv.data(); a.outs = dout.data();
+        family = FE_FAMILY_FACEMASS; flops = 17040.0 * E; bytes = 3072.0 * E;
+    }
+    std::vector<std::vector<float>> t(fns.size());
+    float ms;
+    for (auto f : fns) if (f(family, &a, 3, nullptr, &ms)) { fprintf(stderr, "launch failed\n"); return 3; }
+    for (int r = 0; r < rounds; ++r)
+        for (size_t v = 0; v < fns.size(); ++v) {
+            if (fns[v](family, &a, launches, nullptr, &ms)) return 3;
+            t[v].push_back(ms / launches);
+        }
+    for (size_t v = 0; v < fns.size(); ++v) {
+        std::sort(t[v].begin(), t[v].end());
+        const float med = t[v][t[v].size() / 2];
+        printf("%s E=%lld %-40s median %.4f ms (%.0f GFLOP/s, %.0f GB/s)  min %.4f  max %.4f\n", fam.c_str(),
+               (long long)E, names[v].c_str(), med, flops / med * 1e-6, bytes / med * 1e-6, t[v].front(), t[v].back());
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 7 && std::string(argv[1]) == "ab") return ab_main(argc, argv);
+    if (argc >= 8 && std::string(argv[1]) == "abl") return abl_main(argc, argv);
     if (argc < 3) {
         fprintf(stderr, "usage: fe_check family E [variant] [launches] [check]\n");
         return 1;
