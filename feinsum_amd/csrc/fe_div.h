@@ -54,23 +54,29 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     //      4x4x4_4b: lane (g, n) supplies block n/4, row 32 + n%4 (row 35 = zero padding), k = g.
     //      The 4-row slice is identical for the four blocks, so it lives once in LDS
     //      (3.4 KB per block, broadcast reads) instead of 54 VGPRs per lane.
+    //      D goes through LDS once per block (see stage_operator).
     double abig[kDivBigTiles][kDivJq][3];
-#pragma unroll
-    for (int jq = 0; jq < kDivJq; ++jq) {
-        const int j = 4 * jq + g;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int t = 0; t < kDivBigTiles; ++t)
-                abig[t][jq][r] = (j < kNp35) ? D[(r * kNp35 + 16 * t + n) * kNp35 + j] : 0.0;
-    }
     double* asmall = reinterpret_cast<double*>(smem + sizeof(DivWaveLds) * kDivWavesPerBlock);
-    for (int idx = threadIdx.x; idx < kDivASmallD; idx += 256) {
-        const int ks = idx >> 4, gg = (idx >> 2) & 3, i3 = 32 + (idx & 3);
-        const int j = 4 * (ks / 3) + gg, r = ks % 3;
-        asmall[idx] = (j < kNp35 && i3 < kNp35) ? D[(r * kNp35 + i3) * kNp35 + j] : 0.0;
+    {
+        double* dl = reinterpret_cast<double*>(smem);
+        stage_operator(D, dl, 3 * kNp35 * kNp35);
+        __syncthreads();
+#pragma unroll
+        for (int jq = 0; jq < kDivJq; ++jq) {
+            const int j = 4 * jq + g;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < kDivBigTiles; ++t)
+                    abig[t][jq][r] = (j < kNp35) ? dl[(r * kNp35 + 16 * t + n) * kNp35 + j] : 0.0;
+        }
+        for (int idx = threadIdx.x; idx < kDivASmallD; idx += 256) {
+            const int ks = idx >> 4, gg = (idx >> 2) & 3, i3 = 32 + (idx & 3);
+            const int j = 4 * (ks / 3) + gg, r = ks % 3;
+            asmall[idx] = (j < kNp35 && i3 < kNp35) ? dl[(r * kNp35 + i3) * kNp35 + j] : 0.0;
+        }
+        __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
-    __syncthreads();   // the only block-level barrier: one-time operator staging
     const double* as_lane = asmall + g * 4 + (n & 3);
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
@@ -98,7 +104,10 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     int64_t tile = (int64_t)blockIdx.x * kDivWavesPerBlock + wave;
     bool first = true;
     if (tile < nTiles && !(kDbg & 8)) issue_loads(tile);
+    const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
+    int iteration = 0;
     for (; tile < nTiles; tile += stride) {
+        balance_priority(younger_half, iteration++);
         const int64_t e0 = tile * kTE;
         // issue order: ... L(t) [MFMAs(t-1)] S(t-1) | wait L(t): the previous tile's stores are younger
         if (first || (kDbg & 10)) wait_vmcnt<0>();

@@ -81,20 +81,27 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
     int joff[kFmKSteps];   // offset of J[e0+n][f] inside the J tile
     double abig[kFmBigTiles][kFmKSteps];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
     double asmall[kFmKSteps];              // 4x4x4_4b: block n/4, row 32 + n%4 (row 35 = zero), k = g
+    {
+        // R goes through LDS once per block (see stage_operator)
+        double* rl = reinterpret_cast<double*>(smem);
+        stage_operator(R, rl, kFmNf * kNp35 * kFmNfp);
+        __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < kFmKSteps; ++ks) {
-        const int k = 4 * ks + g;
-        const int f = k / kFmNfp, j = k - f * kFmNfp;
-        voff[ks] = f * kFmSlabD + n * kFmNfp + j;
-        joff[ks] = jfe ? f * kTE + n : n * kFmNf + f;
+        for (int ks = 0; ks < kFmKSteps; ++ks) {
+            const int k = 4 * ks + g;
+            const int f = k / kFmNfp, j = k - f * kFmNfp;
+            voff[ks] = f * kFmSlabD + n * kFmNfp + j;
+            joff[ks] = jfe ? f * kTE + n : n * kFmNf + f;
 #pragma unroll
-        for (int t = 0; t < kFmBigTiles; ++t) {
-            const int i = 16 * t + n;
-            abig[t][ks] = R[rifj ? (i * kFmNf + f) * kFmNfp + j : (f * kNp35 + i) * kFmNfp + j];
+            for (int t = 0; t < kFmBigTiles; ++t) {
+                const int i = 16 * t + n;
+                abig[t][ks] = rl[rifj ? (i * kFmNf + f) * kFmNfp + j : (f * kNp35 + i) * kFmNfp + j];
+            }
+            const int i3 = 32 + (n & 3), i3c = i3 < kNp35 ? i3 : 0;
+            const double a3 = rl[rifj ? (i3c * kFmNf + f) * kFmNfp + j : (f * kNp35 + i3c) * kFmNfp + j];
+            asmall[ks] = (i3 < kNp35) ? a3 : 0.0;
         }
-        const int i3 = 32 + (n & 3), i3c = i3 < kNp35 ? i3 : 0;
-        const double a3 = R[rifj ? (i3c * kFmNf + f) * kFmNfp + j : (f * kNp35 + i3c) * kFmNfp + j];
-        asmall[ks] = (i3 < kNp35) ? a3 : 0.0;
+        __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
 
     const unsigned lds_v0 = lds_addr_uniform(L->v[0]);
@@ -110,7 +117,10 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
     double jv[kFmKSteps];
+    const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
+    int iteration = 0;
     for (int64_t tile = first; tile < nTiles; tile += stride) {
+        balance_priority(younger_half, iteration++);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             // ---- wait for this unit's loads; younger ops: S(m-2), L(m+1), S(m-1)

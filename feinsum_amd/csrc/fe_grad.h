@@ -70,23 +70,39 @@ __device__ __forceinline__ void grad_issue_tile_loads(const double* __restrict__
 constexpr int kGradLoadsPerTile = 10;
 constexpr int kGradStoresPerTile = 15;   // 3 planes x 5 x 16-byte stores
 
+#ifdef FE_EXPERIMENTS
+// Diagnostic build only (kDbg & 32); never read by any kernel, fetched by fe_dbg_read_*():
+// shader cycles / 100 MHz ticks of wave 0's main loop, and per-wave 100 MHz timestamps
+// {kernel entry, main-loop start, main-loop end, XCC_ID | HW_ID << 8}.
+__device__ unsigned long long fe_dbg_clock[2];
+__device__ unsigned long long fe_dbg_stamps[4096][4];
+#endif
+
 // kDbg: experiment flags, 0 in the product build (tools/fe_check.cpp "ab" mode uses the others
 // through build/libfeinsum_hip_exp.so): 1 skip MFMAs, 2 skip stores, 4 plain (temporal) stores,
-// 8 skip loads, 16 plain (temporal) loads.  Product: non-temporal on both sides -- every byte is
-// touched once (A/B on MI355X: -2.5 % kernel time, -7 % for the data-movement skeleton).
+// 8 skip loads, 16 plain (temporal) loads, 32 per-wave timestamps, 64 no priority balancing.
+// Product: non-temporal on both sides -- every byte is touched once (A/B on MI355X: -2.5 %
+// kernel time, -7 % for the data-movement skeleton).
 template <int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
     double* __restrict__ out, int64_t E, int64_t nTiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FE_EXPERIMENTS
+    const unsigned long long t_entry = (kDbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GradWaveLds* L = reinterpret_cast<GradWaveLds*>(smem) + wave;
     const int n = lane & 15, g = lane >> 4;
 
-    // ---- A fragments: lane (g, n) supplies A[row 16t + n][k = 4ks + g]
+    // ---- A fragments: lane (g, n) supplies A[row 16t + n][k = 4ks + g]; D goes through LDS
+    //      once per block (see stage_operator)
     double afrag[kGradRowTiles][kGradKSteps];
     {
+        double* dl = reinterpret_cast<double*>(smem);
+        stage_operator(D, dl, 3 * kNp35 * kNp35);
+        __syncthreads();
         const int gp = n & 3, q = n >> 2;  // C/D lane group / register this row lands in
 #pragma unroll
         for (int t = 0; t < kGradRowTiles; ++t) {
@@ -96,9 +112,10 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
             for (int ks = 0; ks < kGradKSteps; ++ks) {
                 const int j = 4 * ks + g;
                 const bool ok = (s < 27) && (i < kNp35) && (j < kNp35);
-                afrag[t][ks] = ok ? D[(r * kNp35 + i) * kNp35 + j] : 0.0;
+                afrag[t][ks] = ok ? dl[(r * kNp35 + i) * kNp35 + j] : 0.0;
             }
         }
+        __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
 
     const int64_t stride = (int64_t)gridDim.x * kGradWavesPerBlock;
@@ -108,7 +125,14 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
     if (tile < nTiles && !(kDbg & 8))
         grad_issue_tile_loads<(kDbg & 16) == 0>(J, u, E, tile, lane, lds_addr_uniform(L->u[0]), lds_addr_uniform(L->j[0]));
 
+#ifdef FE_EXPERIMENTS
+    unsigned long long c0 = 0, r0 = 0;
+    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const bool younger_half = !(kDbg & 64) && blockIdx.x >= (gridDim.x + 1) / 2;
+    int iteration = 0;
     for (; tile < nTiles; tile += stride, buf ^= 1) {
+        balance_priority(younger_half, iteration++);
         // Vector-memory ops in issue order: L(t) S(t-1) L(t+1) | wait L(t).  The
         // 15 stores of the previous tile and the 10 loads of the next one are
         // younger than this tile's loads and stay in flight.
@@ -118,8 +142,7 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
         } else if (nxt < nTiles) {
             grad_issue_tile_loads<(kDbg & 16) == 0>(J, u, E, nxt, lane, lds_addr_uniform(L->u[buf ^ 1]),
                                   lds_addr_uniform(L->j[buf ^ 1]));
-            if (kDbg & 2) wait_vmcnt<kGradLoadsPerTile>();
-            else if (first) wait_vmcnt<kGradLoadsPerTile>();
+            if ((kDbg & 2) || first) wait_vmcnt<kGradLoadsPerTile>();
             else wait_vmcnt<kGradLoadsPerTile + kGradStoresPerTile>();
         } else {
             if (first || (kDbg & 2)) wait_vmcnt<0>();
@@ -186,6 +209,19 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
             wave_lds_fence();
         }
     }
+#ifdef FE_EXPERIMENTS
+    if ((kDbg & 32) && lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        const int w = blockIdx.x * kGradWavesPerBlock + wave;
+        if (w < 4096) {
+            fe_dbg_stamps[w][0] = t_entry; fe_dbg_stamps[w][1] = r0; fe_dbg_stamps[w][2] = t_end;
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+            fe_dbg_stamps[w][3] = xcc | ((unsigned long long)hw << 8);
+        }
+        if (w == 0) { fe_dbg_clock[0] = __builtin_amdgcn_s_memtime() - c0; fe_dbg_clock[1] = t_end - r0; }
+    }
+#endif
 }
 
 // Plain VALU kernel, any Np: one thread per (e, i), elements [e_begin, E).  Correctness reference on

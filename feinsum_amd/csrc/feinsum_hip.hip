@@ -145,7 +145,7 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
         if (nTiles > 0) {
             int dbg = 0;
 #ifdef FE_EXPERIMENTS
-            if (variant >= 1000) dbg = (variant - 1000) & 31;   // experiment flags, see fe_grad.h
+            if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
 #endif
             const unsigned grid = persistent_grid(nTiles, fe::kGradWavesPerBlock);
             static std::once_flag once;
@@ -155,10 +155,9 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
 #ifdef FE_EXPERIMENTS
                 set_max_lds(fe::grad3d_np35_mfma_kernel<1>, fe::kGradLdsBytes);
                 set_max_lds(fe::grad3d_np35_mfma_kernel<2>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<4>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<16>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<20>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<21>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<32>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<64>, fe::kGradLdsBytes);
+                set_max_lds(fe::grad3d_np35_mfma_kernel<96>, fe::kGradLdsBytes);
 #endif
             });
             if (attr_rc != FE_OK) return attr_rc;
@@ -169,10 +168,9 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
 #ifdef FE_EXPERIMENTS
                 case 1: FE_GRAD_CASE(1); break;
                 case 2: FE_GRAD_CASE(2); break;
-                case 4: FE_GRAD_CASE(4); break;
-                case 16: FE_GRAD_CASE(16); break;
-                case 20: FE_GRAD_CASE(20); break;
-                case 21: FE_GRAD_CASE(21); break;
+                case 32: FE_GRAD_CASE(32); break;
+                case 64: FE_GRAD_CASE(64); break;
+                case 96: FE_GRAD_CASE(96); break;
 #endif
                 default: FE_GRAD_CASE(0); break;
             }
@@ -368,6 +366,19 @@ int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
+
+#ifdef FE_EXPERIMENTS
+int fe_dbg_read_clock(unsigned long long* out2) {
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpyFromSymbol(out2, HIP_SYMBOL(fe::fe_dbg_clock), 16));
+    return FE_OK;
+}
+int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_stamps), (size_t)n_waves * 32));
+    return FE_OK;
+}
+#endif
 
 static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
     switch (family) {

@@ -88,6 +88,48 @@ static int ab_main(int argc, char** argv) {
             FE(fe_time_launches(family, &a, launches, nullptr, &ms));
             t[v].push_back(ms / launches);
         }
+    typedef int (*clk_fn)(unsigned long long*);
+    clk_fn rd = (clk_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_clock");
+    for (size_t v = 0; v < variants.size() && rd; ++v)
+        if (variants[v] >= 1000 && ((variants[v] - 1000) & 32)) {
+            a.variant = variants[v];
+            FE(fe_time_launches(family, &a, launches, nullptr, &ms));
+            unsigned long long c[2];
+            rd(c);
+            printf("variant %d: wave 0 main loop %llu shader cycles in %.1f us -> in-kernel clock %.0f MHz\n",
+                   variants[v], c[0], c[1] / 100.0, (double)c[0] / (double)c[1] * 100.0);
+            typedef int (*st_fn)(unsigned long long*, int);
+            st_fn rs = (st_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_stamps");
+            if (rs) {
+                FE(fe_time_launches(family, &a, 1, nullptr, &ms));   // one isolated launch
+                std::vector<unsigned long long> st4(2048 * 4), st(2048 * 3);
+                rs(st4.data(), 2048);
+                for (int w = 0; w < 2048; ++w) for (int k = 0; k < 3; ++k) st[3 * w + k] = st4[4 * w + k];
+                if (getenv("FE_DUMP_STAMPS")) {
+                    FILE* f = fopen(getenv("FE_DUMP_STAMPS"), "w");
+                    unsigned long long tmin = ~0ull;
+                    for (int w = 0; w < 2048; ++w) tmin = std::min(tmin, st4[4 * w]);
+                    fprintf(f, "wave,xcc,hw_id,entry_us,loop_start_us,loop_end_us\n");
+                    for (int w = 0; w < 2048; ++w)
+                        fprintf(f, "%d,%llu,%llu,%.2f,%.2f,%.2f\n", w, st4[4 * w + 3] & 0xff, st4[4 * w + 3] >> 8,
+                                (st4[4 * w] - tmin) / 100.0, (st4[4 * w + 1] - tmin) / 100.0, (st4[4 * w + 2] - tmin) / 100.0);
+                    fclose(f);
+                }
+                unsigned long long t0 = ~0ull, e_max = 0, l_min = ~0ull, l_max = 0, end_min = ~0ull, end_max = 0;
+                std::vector<double> loop_us, end_us;
+                for (int w = 0; w < 2048; ++w) t0 = std::min(t0, st[3 * w]);
+                for (int w = 0; w < 2048; ++w) {
+                    e_max = std::max(e_max, st[3 * w] - t0);
+                    l_min = std::min(l_min, st[3 * w + 1] - t0); l_max = std::max(l_max, st[3 * w + 1] - t0);
+                    end_min = std::min(end_min, st[3 * w + 2] - t0); end_max = std::max(end_max, st[3 * w + 2] - t0);
+                    end_us.push_back((st[3 * w + 2] - t0) / 100.0);
+                }
+                std::sort(end_us.begin(), end_us.end());
+                printf("  single launch %.1f us by events; waves: last entry +%.1f us, loop start +%.1f..%.1f us, "
+                       "loop end +%.1f (first) %.1f (median) %.1f (p90) %.1f (last) us\n", ms * 1e3, e_max / 100.0,
+                       l_min / 100.0, l_max / 100.0, end_min / 100.0, end_us[1024], end_us[1843], end_max / 100.0);
+            }
+        }
     for (size_t v = 0; v < variants.size(); ++v) {
         std::sort(t[v].begin(), t[v].end());
         const float med = t[v][t[v].size() / 2], mn = t[v].front();
@@ -116,6 +158,7 @@ static int abl_main(int argc, char** argv) {
     fe_argpack a;
     memset(&a, 0, sizeof a);
     a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
+    if (getenv("FE_AB_VARIANT")) a.variant = atoi(getenv("FE_AB_VARIANT"));   // experiment builds only
     int family;
     double flops, bytes;
     std::vector<const double*> dv(b);
