@@ -194,7 +194,9 @@ def main() -> None:
         tfile = ROOT / "profiles" / f"traffic_{args.workload}.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+                rec = json.loads(tfile.read_text())
+                if int(rec.get("E", -1)) == E:      # PMC bytes are per launch AT the profiled size
+                    traffic = rec.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
         ai = flops_step / bytes_step

@@ -83,7 +83,10 @@ def init_distributed(backend: str | None = None) -> DistInfo:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # FEINSUM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals; RCCL refuses that)
+        backend = os.environ.get("FEINSUM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
@@ -111,6 +114,13 @@ def result_reduction(outs: Sequence[Any]) -> Any:
     return torch.stack(rows)
 
 
+def _comm_tensor(t: Any) -> Any:
+    """gloo moves host memory: stage device tensors through the CPU for it (nccl: as is)."""
+    import torch.distributed as dist
+
+    return t.cpu() if (dist.get_backend() == "gloo" and t.is_cuda) else t
+
+
 def allgather_reduction(local: Any) -> Any:
     """All-gather the per-shard reductions -> tensor [world, n_outputs, 3]."""
     import torch
@@ -118,9 +128,10 @@ def allgather_reduction(local: Any) -> Any:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local.unsqueeze(0)
-    gathered = [torch.empty_like(local) for _ in range(dist.get_world_size())]
-    dist.all_gather(gathered, local.contiguous())
-    return torch.stack(gathered)
+    send = _comm_tensor(local.contiguous())
+    gathered = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, send)
+    return torch.stack(gathered).to(local.device)
 
 
 def combine_reductions(gathered: Any) -> Any:
@@ -143,9 +154,10 @@ def allgather_field(local: Any, axis: int, sizes: Sequence[int]) -> Any:
     pad = max(sizes)
     buf = torch.zeros((pad,) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
     buf[: moved.shape[0]] = moved
+    buf = _comm_tensor(buf)
     parts: List[Any] = [torch.empty_like(buf) for _ in sizes]
     dist.all_gather(parts, buf)
-    full = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+    full = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0).to(local.device)
     return full.movedim(0, axis).contiguous()
 
 
@@ -162,6 +174,7 @@ def max_over_ranks(value: float, device: Any = None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=on)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
