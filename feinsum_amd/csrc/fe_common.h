@@ -84,9 +84,32 @@ __device__ __forceinline__ void wave_lds_fence() {
 // block's LDS, all threads, coalesced.  Caller synchronises.  (2048 waves each gathering their
 // MFMA fragments of the same ~30 KB straight from L2 cost up to 18 us of prologue; staged once
 // per block it is ~5 us and the whole kernel ran 9 % faster in A/B.)
-__device__ __forceinline__ void stage_operator(const double* __restrict__ g, double* lds, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = g[i];
+template <int N>
+__device__ __forceinline__ void stage_operator(const double* __restrict__ g, double* lds) {
+    // 256-thread blocks; all loads are issued before the first LDS write so that their latencies
+    // overlap (a plain copy loop waits for each load in turn: ~15 dependent L2 round trips).
+    constexpr int kPer = (N + 255) / 256;
+    double tmp[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = threadIdx.x + k * 256;
+        tmp[k] = (i < N) ? g[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i < N) lds[i] = tmp[k];
+    }
 }
+
+// Tried and rejected for balancing ACROSS CUs (a few CUs finish ~10 % late): tile tickets from
+// global atomic counters.  One counter retires only ~88 atomics/us (the kernels consume ~300
+// tiles/us); eight per-XCD counters with the ticket taken one or two iterations ahead still
+// cost +11...23 % kernel time, because gfx950 executes every global atomic at the memory side
+// (the compiler emits the same instruction for workgroup and agent scope) and the ~62 500
+// read-modify-writes keep their eight HBM channels busy, which gates the interleaved
+// streaming traffic.  A block-local LDS ticket counter (one 512-thread block per CU) balances
+// only inside a CU and was slower than two independent 256-thread blocks.  See DESIGN.md.
 
 // Issue-arbitration balance between the two waves of a SIMD.  With two 256-thread blocks per CU
 // the wave of the block dispatched first is the older one on every SIMD and wins instruction

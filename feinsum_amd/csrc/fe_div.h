@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
     double* asmall = reinterpret_cast<double*>(smem + sizeof(DivWaveLds) * kDivWavesPerBlock);
     {
         double* dl = reinterpret_cast<double*>(smem);
-        stage_operator(D, dl, 3 * kNp35 * kNp35);
+        stage_operator<3 * kNp35 * kNp35>(D, dl);
         __syncthreads();
 #pragma unroll
         for (int jq = 0; jq < kDivJq; ++jq) {

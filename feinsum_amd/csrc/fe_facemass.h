@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
     {
         // R goes through LDS once per block (see stage_operator)
         double* rl = reinterpret_cast<double*>(smem);
-        stage_operator(R, rl, kFmNf * kNp35 * kFmNfp);
+        stage_operator<kFmNf * kNp35 * kFmNfp>(R, rl);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < kFmKSteps; ++ks) {

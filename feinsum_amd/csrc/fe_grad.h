@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void grad3d_np35_mfma_kernel(
     double afrag[kGradRowTiles][kGradKSteps];
     {
         double* dl = reinterpret_cast<double*>(smem);
-        stage_operator(D, dl, 3 * kNp35 * kNp35);
+        stage_operator<3 * kNp35 * kNp35>(D, dl);
         __syncthreads();
         const int gp = n & 3, q = n >> 2;  // C/D lane group / register this row lands in
 #pragma unroll
