@@ -7,6 +7,7 @@ path (reference: ``src/feinsum/__init__.py:1-68``); everything loopy-, sqlite-
 or autotuner-related is out of scope and absent.
 """
 
+from feinsum_amd.cl_utils import FakeCLDevice
 from feinsum_amd.contraction_schedule import (ContractionSchedule, count_ops,
                                               get_opt_einsum_contraction_schedule,
                                               get_trivial_contraction_schedule)
@@ -24,7 +25,7 @@ from feinsum_amd.measure import (DeviceQueue, evaluate, generate_input_arrays, g
 
 __all__ = (
     "Array", "BatchedEinsum", "ContractionSchedule", "DeviceQueue", "EinsumAxisAccess",
-    "EinsumTunitMatchError", "FreeAxis", "HipLibraryError", "InvalidParameterError", "KernelPlan",
+    "EinsumTunitMatchError", "FakeCLDevice", "FreeAxis", "HipLibraryError", "InvalidParameterError", "KernelPlan",
     "NoDevicePeaksInfoError", "NoFactInDatabaseError", "SizeParam", "SummationAxis",
     "TransformValidationError", "array", "batched_einsum", "count_ops", "einsum", "evaluate",
     "generate_input_arrays", "generate_out_arrays", "get_opt_einsum_contraction_schedule",

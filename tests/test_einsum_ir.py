@@ -92,3 +92,13 @@ def test_whitespace_and_parametric_matvec():
                                         [A, f.array("y", 4, "float32")]])
     assert e.b == 2 and e.shape == (SizeParam("I"),)
     assert e.get_subscripts() == "ij,j -> i"
+
+
+def test_api_parity_helpers():
+    from feinsum_amd.typing import TransformT
+
+    assert f.FakeCLDevice("AMD Instinct MI355X").name == "AMD Instinct MI355X"
+    ident: TransformT = lambda t_unit, insn_match=None, kernel_name=None: t_unit  # noqa: E731
+    assert ident(1) == 1
+    r = f.get_roofline_flop_rate(dg.grad(), f.FakeCLDevice("AMD Instinct MI355X").name, 1_000_000)
+    assert r[np.dtype("float64")] > 5e4
