@@ -79,6 +79,45 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
+template <int NP, int M>
+int launch_grad(const double* J, const double* D, const double* u, double* out, int64_t E,
+                int dbg, hipStream_t s, int64_t* e_done) {
+    using G = fe::GradGeom<NP, M>;
+    const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
+    *e_done = nTiles * G::TEL;
+    if (nTiles == 0) return FE_OK;
+    static std::once_flag once;
+    static int attr_rc = FE_OK;
+    std::call_once(once, [] {
+        attr_rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+#ifdef FE_EXPERIMENTS
+        if (NP == 35) {
+            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
+            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 2>, G::LDS_BYTES);
+            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 32>, G::LDS_BYTES);
+            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 64>, G::LDS_BYTES);
+            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 96>, G::LDS_BYTES);
+        }
+#endif
+    });
+    if (attr_rc != FE_OK) return attr_rc;
+    const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
+#define FE_GRAD_CASE(DBG) \
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles)
+    switch (NP == 35 ? dbg : 0) {
+#ifdef FE_EXPERIMENTS
+        case 1: FE_GRAD_CASE(1); break;
+        case 2: FE_GRAD_CASE(2); break;
+        case 32: FE_GRAD_CASE(32); break;
+        case 64: FE_GRAD_CASE(64); break;
+        case 96: FE_GRAD_CASE(96); break;
+#endif
+        default: FE_GRAD_CASE(0); break;
+    }
+#undef FE_GRAD_CASE
+    return FE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,47 +175,23 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
         return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool mfma_ok = (Np == fe::kNp35);
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
     if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np == 35 only (Np=%d)", Np);
+        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
     int64_t e_done = 0;
     if (variant != FE_VARIANT_GENERIC && mfma_ok) {
-        const int64_t nTiles = E / fe::kTE;   // full tiles; the remainder goes to the generic kernel
-        if (nTiles > 0) {
-            int dbg = 0;
+        int dbg = 0;
 #ifdef FE_EXPERIMENTS
-            if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
+        if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
 #endif
-            const unsigned grid = persistent_grid(nTiles, fe::kGradWavesPerBlock);
-            static std::once_flag once;
-            static int attr_rc = FE_OK;
-            std::call_once(once, [] {
-                attr_rc = set_max_lds(fe::grad3d_np35_mfma_kernel<0>, fe::kGradLdsBytes);
-#ifdef FE_EXPERIMENTS
-                set_max_lds(fe::grad3d_np35_mfma_kernel<1>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<2>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<32>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<64>, fe::kGradLdsBytes);
-                set_max_lds(fe::grad3d_np35_mfma_kernel<96>, fe::kGradLdsBytes);
-#endif
-            });
-            if (attr_rc != FE_OK) return attr_rc;
-            const dim3 g(grid), b(256);
-#define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL(fe::grad3d_np35_mfma_kernel<DBG>, g, b, fe::kGradLdsBytes, s, J, D, u, out, E, nTiles)
-            switch (dbg) {
-#ifdef FE_EXPERIMENTS
-                case 1: FE_GRAD_CASE(1); break;
-                case 2: FE_GRAD_CASE(2); break;
-                case 32: FE_GRAD_CASE(32); break;
-                case 64: FE_GRAD_CASE(64); break;
-                case 96: FE_GRAD_CASE(96); break;
-#endif
-                default: FE_GRAD_CASE(0); break;
-            }
-#undef FE_GRAD_CASE
-            e_done = nTiles * fe::kTE;
+        int rc = FE_OK;
+        switch (Np) {   // wave tile = 16 M elements
+            case 35: rc = launch_grad<35, 1>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 20: rc = launch_grad<20, 2>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 10: rc = launch_grad<10, 3>(J, D, u, out, E, dbg, s, &e_done); break;
+            default: rc = launch_grad<4, 5>(J, D, u, out, E, dbg, s, &e_done); break;
         }
+        if (rc != FE_OK) return rc;
     }
     if (e_done < E)
         hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,

@@ -79,9 +79,21 @@ def test_forced_mfma_variant(torch_cuda, fam):
     expr = FAMILIES[fam]()
     host = generate_host_input_arrays(expr, 4096, np_seed=5)
     _assert_close(_run(torch_cuda, expr, host, transform={"variant": "mfma"}), _oracle(expr, host))
-    with pytest.raises(NotImplementedError):   # FE_EUNSUPPORTED: Np = 10 is not compiled for MFMA
-        e10 = dg.grad(10)
-        _run(torch_cuda, e10, generate_host_input_arrays(e10, 64), transform="mfma")
+    with pytest.raises(NotImplementedError):   # FE_EUNSUPPORTED: Np = 56 (p = 5) is not compiled for MFMA
+        e56 = dg.grad(56)
+        _run(torch_cuda, e56, generate_host_input_arrays(e56, 64), transform="mfma")
+
+
+@pytest.mark.parametrize("Np", [4, 10, 20])
+@pytest.mark.parametrize("E", [15, 16, 79, 80, 81, 1000, 10007])
+def test_grad_lower_orders_mfma(torch_cuda, Np, E):
+    # p = 1, 2, 3: the (Np, M) instantiations of the grad template; wave tiles of 80 / 48 / 32
+    # elements, so E around those sizes exercises tile + generic-remainder splits
+    expr = dg.grad(Np)
+    host = generate_host_input_arrays(expr, E, np_seed=Np + E)
+    ref = _oracle(expr, host)
+    _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
+    _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
 
 
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])

@@ -59,7 +59,7 @@ static int ab_main(int argc, char** argv) {
     const int rounds = atoi(argv[4]), launches = atoi(argv[5]);
     std::vector<int> variants;
     for (char* tok = strtok(argv[6], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
-    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
     fe_argpack a;
     memset(&a, 0, sizeof a);
     a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
@@ -154,7 +154,7 @@ static int abl_main(int argc, char** argv) {
         fns.push_back((time_fn)dlsym(h, "fe_time_launches"));
         names.push_back(argv[i]);
     }
-    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
     fe_argpack a;
     memset(&a, 0, sizeof a);
     a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
@@ -204,7 +204,7 @@ int main(int argc, char** argv) {
     const int variant = argc > 3 ? atoi(argv[3]) : 0;
     const int launches = argc > 4 ? atoi(argv[4]) : 20;
     const int check = argc > 5 ? atoi(argv[5]) : 1;
-    const int Np = 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
 
     char name[256];
     double pf, pb;
@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
         else if (fam == "div") { family = FE_FAMILY_DIV; a.u = v; a.out = od; }
         else { family = FE_FAMILY_GRADDIV; a.u = u; a.v_div = v; a.out = og; a.out2 = od; }
         flops = (double)fe_flops_per_element(family, Np, 0, 0, 0) * E;
-        bytes = (family == FE_FAMILY_GRADDIV ? 8.0 * (9 + 35 + 105 + 105 + 35) : 8.0 * 149) * E +
+        bytes = (family == FE_FAMILY_GRADDIV ? 8.0 * (9 + 8 * Np) : 8.0 * (9 + 4 * Np)) * E +
                 8.0 * 3 * Np * Np;
         float w;
         FE(fe_time_launches(family, &a, 3, nullptr, &w));  // warm-up
