@@ -7,73 +7,90 @@
 // Jacobian contraction  Ju[r,e,j] = sum_x J[x,r,e] u[x,e,j]  (VALU, 3 FMAs per
 // value, produced directly in MFMA B-fragment layout and kept in registers),
 // then the dense one  out[i, e] = sum_{(j,r)} D'[i, (j,r)] * Ju[(j,r), e]  on the
-// matrix cores, A = D' (35 x 105, K padded to 108) resident in registers:
-//   rows  0..31  two 16-row tiles on v_mfma_f64_16x16x4_f64   (2 x 27 MFMAs, 64 cycles each)
-//   rows 32..34  on v_mfma_f64_4x4x4_4b_f64: its four 4x4x4 blocks are four groups of
-//                four elements sharing one (replicated) 4-row slice of D', so the 3
-//                leftover rows cost 27 x 16 cycles instead of a third 16-row tile
-//                (27 x 64).  Its B operand layout (lane = 16 k + column) is the
-//                16x16x4 one, so the same B registers feed both instructions.
+// matrix cores, A = D' (Np x 3 Np, K padded to 3 * 4 * ceil(Np/4)):
+//   rows 0 .. 16 BT - 1   BT = Np / 16 tiles on v_mfma_f64_16x16x4_f64 (64 cycles each),
+//                         A fragments resident in registers;
+//   the NR = Np - 16 BT   remaining rows in groups of four on v_mfma_f64_4x4x4_4b_f64: its four
+//                         4x4x4 blocks are four groups of four elements sharing one
+//                         (replicated) 4-row slice of D', so a group costs 16 cycles per
+//                         k-step instead of a whole 16-row tile (64).  Its B operand layout
+//                         (lane = 16 k + column) is the 16x16x4 one, so the same B registers
+//                         feed both instructions; its 4-row A slices live in LDS (broadcast
+//                         reads) instead of VGPRs.
+//   Np 35: BT 2 + 1 group (rows 32-34);  20: BT 1 + 1 group;  10: 3 groups;  4: 1 group.
 // K is ordered (jq, r) with j = 4 jq + g: one group of three u values (x = 0..2)
 // feeds three consecutive k-steps.
-// Data movement as in fe_grad.h.  The three u planes (13.4 KB per wave) leave
-// no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a
-// tile are computed up front (27 doubles / lane), which frees the u buffer, and
-// the next tile's loads are issued before this tile's MFMAs and stores.
+// Data movement as in fe_grad.h; a wave tile is 16 M elements.  The three u planes of a tile
+// leave no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a tile are
+// computed up front, which frees the u buffer, and the next tile's loads are issued before
+// this tile's MFMAs and stores.
 #pragma once
 #include "fe_grad.h"
 
 namespace fe {
 
-constexpr int kDivBigTiles = 2;   // rows 0..31
-constexpr int kDivJq = 9;         // 35 -> 36 j's, 4 per k-step
-
-struct DivWaveLds {
-    double u[3][kTileD35];    // u[x][e0..e0+15][0..34]
-    double o[kTileD35];       // output transposition buffer
-    double j[9 * kTE];        // J[x*3+r][e0 + 0..15]
+template <int NP, int M>
+struct DivGeom {
+    static constexpr int TEL = 16 * M;
+    static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = 3 KSJ, ordered (jq, r)
+    static constexpr int BT = NP / 16;                  // 16-row tiles
+    static constexpr int NR = NP - 16 * BT;             // rows left for the 4x4x4 groups
+    static constexpr int NS = (NR + 3) / 4;             // 4-row groups
+    static constexpr int PLANE_D = TEL * NP;            // doubles: one u plane of a tile / the out tile
+    static constexpr int SUB_D = 16 * NP;
+    static constexpr int P_CHUNKS = PLANE_D / 2, P_INSTR = (P_CHUNKS + 63) / 64;
+    static constexpr int J_ROW_CHUNKS = TEL / 2, J_CHUNKS = 9 * J_ROW_CHUNKS, J_INSTR = (J_CHUNKS + 63) / 64;
+    static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
+    static constexpr int LOADS = 3 * P_INSTR + J_INSTR, STORES = M * SUB_INSTR;
+    struct WaveLds {
+        double u[3][PLANE_D];     // u[x][e0 .. e0+TEL-1][0..Np-1]
+        double o[SUB_D];          // output transposition buffer (one 16-element sub-tile)
+        double j[9 * TEL];        // J[x*3+r][e0 + 0..TEL-1]
+    };
+    static constexpr int WAVES = 4;
+    static constexpr int ASMALL_D = 3 * KSJ * NS * 16;  // [k-step][group][g][row] doubles, per block
+    static constexpr int OP_D = 3 * NP * NP;
+    static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
+    static constexpr int LDS_BYTES = (WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8) + ASMALL_D * 8;
+    static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 };
-static_assert(sizeof(DivWaveLds) == 19072, "LDS budget");
-constexpr int kDivWavesPerBlock = 4;
-constexpr int kDivASmallD = 27 * 4 * 4;   // D' rows 32..35 as [k-step][g][row], shared by the block
-constexpr int kDivLdsBytes = sizeof(DivWaveLds) * kDivWavesPerBlock + kDivASmallD * 8;  // 79744: 2 blocks / CU
-constexpr int kDivLoadsPerTile = 20, kDivStoresPerTile = 5;
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int kDbg = 0>
-__global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
+template <int NP, int M, int kDbg = 0>
+__global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
     double* __restrict__ out, int64_t E, int64_t nTiles) {
+    using G = DivGeom<NP, M>;
+    using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    DivWaveLds* L = reinterpret_cast<DivWaveLds*>(smem) + wave;
+    WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;
     const int n = lane & 15, g = lane >> 4;
 
-    // ---- A fragments.  16x16x4: lane (g, n) supplies A[row 16t + n][k = g];
-    //      4x4x4_4b: lane (g, n) supplies block n/4, row 32 + n%4 (row 35 = zero padding), k = g.
-    //      The 4-row slice is identical for the four blocks, so it lives once in LDS
-    //      (3.4 KB per block, broadcast reads) instead of 54 VGPRs per lane.
-    //      D goes through LDS once per block (see stage_operator).
-    double abig[kDivBigTiles][kDivJq][3];
-    double* asmall = reinterpret_cast<double*>(smem + sizeof(DivWaveLds) * kDivWavesPerBlock);
+    // ---- A fragments from the LDS-staged operator.  16x16x4: lane (g, n) supplies
+    //      A[row 16t + n][k = g];  4x4x4_4b group q: lane (g, n) supplies block n/4, row
+    //      16 BT + 4q + n%4, k = g -- identical for the four blocks, kept once in LDS.
+    double abig[G::BT > 0 ? G::BT : 1][G::KSJ][3];
+    double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - G::ASMALL_D * 8));
     {
         double* dl = reinterpret_cast<double*>(smem);
-        stage_operator<3 * kNp35 * kNp35>(D, dl);
+        stage_operator<G::OP_D>(D, dl);
         __syncthreads();
 #pragma unroll
-        for (int jq = 0; jq < kDivJq; ++jq) {
+        for (int jq = 0; jq < G::KSJ; ++jq) {
             const int j = 4 * jq + g;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int t = 0; t < kDivBigTiles; ++t)
-                    abig[t][jq][r] = (j < kNp35) ? dl[(r * kNp35 + 16 * t + n) * kNp35 + j] : 0.0;
+                for (int t = 0; t < G::BT; ++t)
+                    abig[t][jq][r] = (j < NP) ? dl[(r * NP + 16 * t + n) * NP + j] : 0.0;
         }
-        for (int idx = threadIdx.x; idx < kDivASmallD; idx += 256) {
-            const int ks = idx >> 4, gg = (idx >> 2) & 3, i3 = 32 + (idx & 3);
-            const int j = 4 * (ks / 3) + gg, r = ks % 3;
-            asmall[idx] = (j < kNp35 && i3 < kNp35) ? dl[(r * kNp35 + i3) * kNp35 + j] : 0.0;
+        for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
+            const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
+            const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / 3) + gg, r = ks % 3;
+            asmall[idx] = (j < NP && i < NP) ? dl[(r * NP + i) * NP + j] : 0.0;
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
@@ -81,110 +98,129 @@ __global__ __launch_bounds__(256, 2) void div3d_np35_mfma_kernel(
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
-    const int64_t stride = (int64_t)gridDim.x * kDivWavesPerBlock;
-    // 3 planes x 5 x 16-byte LDS-DMA + 5 x 4-byte LDS-DMA for J = 20 vector-memory ops
+    const int64_t stride = (int64_t)gridDim.x * G::WAVES;
     auto issue_loads = [&](int64_t tile) {
-        const int64_t e0 = tile * kTE;
-        const char* ub = reinterpret_cast<const char*>(u) + e0 * (kNp35 * 8) + lane * 16;
+        const int64_t e0 = tile * G::TEL;
+        const char* ub = reinterpret_cast<const char*>(u) + e0 * (NP * 8) + lane * 16;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            const char* up = ub + (int64_t)x * E * (kNp35 * 8);
+            const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
-            for (int c = 0; c < 5; ++c)
-                if (c < 4 || lane < 24) glds16_nt(up + c * 1024, lds_u + x * kTileB35 + c * 1024);
+            for (int c = 0; c < G::P_INSTR; ++c)
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                    glds16_nt(up + c * 1024, lds_u + x * (G::PLANE_D * 8) + c * 1024);
         }
-        const int w = lane & 31;
-        const char* jb = reinterpret_cast<const char*>(J) + e0 * 8 + w * 4;
+        const char* jb = reinterpret_cast<const char*>(J) + e0 * 8;
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
-            const int row = 2 * p + (lane >> 5);
-            if (p < 4 || lane < 32) glds4(jb + (int64_t)row * E * 8, lds_j + p * 256);
+        for (int c = 0; c < G::J_INSTR; ++c) {
+            const int q = c * 64 + lane;
+            const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
+            if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS)
+                glds16(jb + ((int64_t)row * E) * 8 + col * 16, lds_j + c * 1024);
         }
     };
-    int64_t tile = (int64_t)blockIdx.x * kDivWavesPerBlock + wave;
+    int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
     bool first = true;
     if (tile < nTiles && !(kDbg & 8)) issue_loads(tile);
     const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
     int iteration = 0;
     for (; tile < nTiles; tile += stride) {
         balance_priority(younger_half, iteration++);
-        const int64_t e0 = tile * kTE;
+        const int64_t e0 = tile * G::TEL;
         // issue order: ... L(t) [MFMAs(t-1)] S(t-1) | wait L(t): the previous tile's stores are younger
         if (first || (kDbg & 10)) wait_vmcnt<0>();
-        else wait_vmcnt<kDivStoresPerTile>();
+        else wait_vmcnt<G::STORES>();
         first = false;
 
-        // ---- all B fragments: Ju[(jq, r)][e = n], j = 4 jq + g
-        double jac[9];
+        // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
+        double bfrag[M][G::KSJ][3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) jac[k] = L->j[k * kTE + n];   // jac[x*3 + r]
-        double bfrag[kDivJq][3];
+        for (int m = 0; m < M; ++m) {
+            double jac[9];
 #pragma unroll
-        for (int jq = 0; jq < kDivJq; ++jq) {
-            const int j = 4 * jq + g;
-            const int jc = j < kNp35 ? j : 0;
-            double u0 = L->u[0][n * kNp35 + jc];
-            double u1 = L->u[1][n * kNp35 + jc];
-            double u2 = L->u[2][n * kNp35 + jc];
-            if (j >= kNp35) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
+            for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + 16 * m + n];   // jac[x*3 + r]
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-                bfrag[jq][r] = jac[0 * 3 + r] * u0 + jac[1 * 3 + r] * u1 + jac[2 * 3 + r] * u2;
+            for (int jq = 0; jq < G::KSJ; ++jq) {
+                const int j = 4 * jq + g;
+                const int jc = j < NP ? j : 0;
+                double u0 = L->u[0][(16 * m + n) * NP + jc];
+                double u1 = L->u[1][(16 * m + n) * NP + jc];
+                double u2 = L->u[2][(16 * m + n) * NP + jc];
+                if (j >= NP) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    bfrag[m][jq][r] = jac[0 * 3 + r] * u0 + jac[1 * 3 + r] * u1 + jac[2 * 3 + r] * u2;
+            }
         }
         // the u / J tiles are now in registers: hand the buffers back to the DMA engine
 #pragma unroll
-        for (int jq = 0; jq < kDivJq; ++jq)
+        for (int m = 0; m < M; ++m)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
+            for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
         if (tile + stride < nTiles && !(kDbg & 8)) issue_loads(tile + stride);
 
-        // ---- 54 + 27 MFMAs
-        v4d acc[kDivBigTiles];
-        double acc3 = 0.0;
 #pragma unroll
-        for (int t = 0; t < kDivBigTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-        if (kDbg & 1) {
-            double sum = 0.0;
+        for (int m = 0; m < M; ++m) {
+            // ---- BT x 3 KSJ big + NS x 3 KSJ small MFMAs
+            v4d acc[G::BT > 0 ? G::BT : 1];
+            double accs[G::NS > 0 ? G::NS : 1];
 #pragma unroll
-            for (int jq = 0; jq < kDivJq; ++jq)
+            for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int r = 0; r < 3; ++r) sum += bfrag[jq][r];
-            acc[0] = v4d{sum, sum, sum, sum}; acc[1] = acc[0]; acc3 = sum + abig[0][0][0] + abig[1][8][2];
-        } else {
+            for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+            if (kDbg & 1) {
+                double sum = 0.0;
 #pragma unroll
-            for (int jq = 0; jq < kDivJq; ++jq)
+                for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                    for (int r = 0; r < 3; ++r) sum += bfrag[m][jq][r];
 #pragma unroll
-                    for (int t = 0; t < kDivBigTiles; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[jq][r], acc[t], 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[(jq * 3 + r) * 16], bfrag[jq][r], acc3, 0, 0, 0);
-                }
-        }
-
-        // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e0 + n][16t + g + 4q];
-        //      4x4x4_4b D: lane (g, n) holds out[e0 + n][32 + g] (g == 3 is padding)
-        double* ob = L->o;
+                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{sum, sum, sum, abig[t][0][0]};
 #pragma unroll
-        for (int t = 0; t < kDivBigTiles; ++t)
+                for (int q = 0; q < G::NS; ++q) accs[q] = sum;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ob[n * kNp35 + 16 * t + g + 4 * q] = acc[t][q];
-        if (g < 3) ob[n * kNp35 + 32 + g] = acc3;
-        wave_lds_fence();
-        double* op = out + e0 * kNp35;
+                for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            if (c < 4 || lane < 24) {
-                const int q = c * 64 + lane;
-                const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * q] = val[1]; }
-                else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int t = 0; t < G::BT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[m][jq][r], acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < G::NS; ++q)
+                            accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16],
+                                                                         bfrag[m][jq][r], accs[q], 0, 0, 0);
+                    }
             }
+
+            // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e][16t + g + 4q'];
+            //      4x4x4_4b D of group q: lane (g, n) holds out[e][16 BT + 4q + g]
+            double* ob = L->o;
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) {
+                const int i = 16 * G::BT + 4 * q + g;
+                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+            }
+            wave_lds_fence();
+            double* op = out + (e0 + 16 * m) * NP;
+#pragma unroll
+            for (int c = 0; c < G::SUB_INSTR; ++c) {
+                const int qc = c * 64 + lane;
+                if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
+                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                    if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * qc] = val[1]; }
+                    else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();
     }
 }
-
-inline bool div_mfma_supported(int Np) { return Np == kNp35; }
 
 }  // namespace fe

@@ -7,116 +7,138 @@
 // Schedule = the opt_einsum-optimal one: Jv_k[(f,j), e] = J[e,f] v_k[f,e,j] (one
 // multiply, VALU, produced in MFMA B-fragment layout), then
 //   out_k[i, e] = sum_{(f,j)} R'[i, (f,j)] * Jv_k[(f,j), e]
-// on the matrix cores, A = R' (35 x 60; K = 60 = 15 k-steps exactly) resident in
-// registers (45 doubles / lane): rows 0..31 as two 16-row tiles on
-// v_mfma_f64_16x16x4_f64 (2 x 15 MFMAs of 64 cycles) and rows 32..34 on
-// v_mfma_f64_4x4x4_4b_f64 (15 x 16 cycles; see fe_div.h) per (16-element tile,
-// field) "unit" per wave.
-// Data movement: a unit's four face slabs (4 x 1920 contiguous bytes) come in
-// by LDS-DMA into a 2-slot ring, two units ahead; J for a tile (512 B) comes with
-// its first unit; results leave through a separate LDS transposition buffer as
-// 1-KiB contiguous stores.  Loads for unit m+2 are issued as soon as unit m's B
-// fragments are in registers, i.e. BEFORE unit m's MFMAs and stores, so the
-// counted vmcnt at the top of a unit never waits for stores.
+// on the matrix cores, A = R' (Np x 4 Nfp; K = 4 Nfp = Nfp k-steps exactly) resident in
+// registers: rows 0 .. 16 BT - 1 as BT = Np / 16 tiles on v_mfma_f64_16x16x4_f64 and the remaining
+// rows in groups of four on v_mfma_f64_4x4x4_4b_f64 (see fe_div.h), per (wave tile, field) "unit".
+// Templated on the tetrahedral orders p = 1..4: (Np, Nfp) = (4,3), (10,6), (20,10), (35,15), and
+// on M: a wave tile is 16 M elements.
+// Data movement: a unit's four face slabs (4 x 16 M Nfp contiguous doubles) come in by LDS-DMA
+// into a 2-slot ring, two units ahead; J for a tile comes with its first unit; results leave
+// through a separate LDS transposition buffer as contiguous 16-byte-per-lane stores.  Loads for
+// unit m+2 are issued as soon as unit m's B fragments are in registers, i.e. BEFORE unit m's
+// MFMAs and stores, so the counted vmcnt at the top of a unit never waits for stores.
 #pragma once
 #include "fe_generic.h"
 #include "fe_grad.h"
 
 namespace fe {
 
-constexpr int kFmNf = 4, kFmNfp = 15;
-constexpr int kFmSlabD = kTE * kFmNfp;            // 240 doubles = 1920 bytes per face
-constexpr int kFmUnitD = kFmNf * kFmSlabD;        // 960 doubles = 7680 bytes
-constexpr int kFmKSteps = 15;                     // K = 60
-constexpr int kFmBigTiles = 2;                    // rows 0..31; rows 32..34 on 4x4x4_4b
+constexpr int kFmNf = 4;
 
-struct FmWaveLds {
-    double v[2][kFmUnitD];     // ring of field slabs: v[slot][f][e][j]
-    double o[kTileD35];        // output transposition buffer
-    double j[kFmNf * kTE];     // J tile, [e][f] or [f][e] as in global memory
+template <int NP, int NFP, int M>
+struct FmGeom {
+    static constexpr int TEL = 16 * M;
+    static constexpr int KS = NFP;                      // K = 4 NFP = NFP k-steps of 4
+    static constexpr int BT = NP / 16, NR = NP - 16 * BT, NS = (NR + 3) / 4;
+    static constexpr int SLAB_D = TEL * NFP;            // doubles per face slab of a unit
+    static constexpr int UNIT_D = kFmNf * SLAB_D;
+    static constexpr int SUB_D = 16 * NP;
+    static constexpr int SLAB_CHUNKS = SLAB_D / 2, SLAB_INSTR = (SLAB_CHUNKS + 63) / 64;
+    static constexpr int J_CHUNKS = 2 * TEL, J_INSTR = (J_CHUNKS + 63) / 64;   // 4 TEL doubles
+    static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
+    static constexpr int UNIT_LOADS = kFmNf * SLAB_INSTR;   // + J_INSTR at a tile start
+    static constexpr int UNIT_STORES = M * SUB_INSTR;
+    struct WaveLds {
+        double v[2][UNIT_D];     // ring of field slabs: v[slot][f][e][j]
+        double o[SUB_D];         // output transposition buffer (one 16-element sub-tile)
+        double j[kFmNf * TEL];   // J tile, [e][f] or [f][e] as in global memory
+    };
+    static constexpr int WAVES = 4;
+    static constexpr int OP_D = kFmNf * NP * NFP;
+    static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
+    static constexpr int LDS_BYTES = WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8;
+    static_assert((TEL * NFP) % 2 == 0, "slabs are moved in 16-byte chunks");
+    static_assert(2 * UNIT_STORES + UNIT_LOADS + J_INSTR <= 60, "counted vmcnt must fit the 6-bit field");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 };
-static_assert(sizeof(FmWaveLds) == 20352, "LDS budget");
-constexpr int kFmWavesPerBlock = 4;
-constexpr int kFmLdsBytes = sizeof(FmWaveLds) * kFmWavesPerBlock;  // 81408: 2 blocks / CU
-constexpr int kFmStoresPerUnit = 5;
 
-// 8 x 16-byte LDS-DMA for the field slabs (+ 2 x 4-byte for J at a tile start).
-template <bool kWithJ>
+// UNIT_LOADS x 16-byte LDS-DMA for the field slabs (+ J_INSTR for J at a tile start).
+template <int NP, int NFP, int M, bool kWithJ>
 __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J,
                                                     const double* __restrict__ vk, int64_t E,
                                                     int64_t tile, int lane, unsigned lds_v,
                                                     unsigned lds_j, int jfe) {
-    const int64_t e0 = tile * kTE;
-    const char* vb = reinterpret_cast<const char*>(vk) + e0 * (kFmNfp * 8) + lane * 16;
+    using G = FmGeom<NP, NFP, M>;
+    const int64_t e0 = tile * G::TEL;
+    const char* vb = reinterpret_cast<const char*>(vk) + e0 * (NFP * 8) + lane * 16;
 #pragma unroll
     for (int f = 0; f < kFmNf; ++f) {
-        const char* vf = vb + (int64_t)f * E * (kFmNfp * 8);
-        glds16_nt(vf, lds_v + f * (kFmSlabD * 8));
-        if (lane < 56) glds16_nt(vf + 1024, lds_v + f * (kFmSlabD * 8) + 1024);
+        const char* vf = vb + (int64_t)f * E * (NFP * 8);
+#pragma unroll
+        for (int c = 0; c < G::SLAB_INSTR; ++c)
+            if ((c + 1) * 64 <= G::SLAB_CHUNKS || c * 64 + lane < G::SLAB_CHUNKS)
+                glds16_nt(vf + c * 1024, lds_v + f * (G::SLAB_D * 8) + c * 1024);
     }
     if (kWithJ) {
         const char* jb = reinterpret_cast<const char*>(J);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const char* src = jfe ? jb + ((int64_t)(2 * p + (lane >> 5)) * E + e0) * 8 + (lane & 31) * 4
-                                  : jb + e0 * (kFmNf * 8) + (p * 64 + lane) * 4;
-            glds4(src, lds_j + p * 256);
+        for (int c = 0; c < G::J_INSTR; ++c) {
+            const int q = c * 64 + lane;                       // 16-byte chunk of the J tile
+            const int row = q / (G::TEL / 2), col = q - row * (G::TEL / 2);   // "fe": 4 rows of TEL doubles
+            const char* src = jfe ? jb + ((int64_t)row * E + e0) * 8 + col * 16
+                                  : jb + e0 * (kFmNf * 8) + q * 16;
+            if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
+template <int NP, int NFP, int M, int NB>
+__global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
     int64_t nTiles, int jfe, int rifj) {
+    using G = FmGeom<NP, NFP, M>;
+    using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FmWaveLds* L = reinterpret_cast<FmWaveLds*>(smem) + wave;
+    WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;
     const int n = lane & 15, g = lane >> 4;
 
-    // ---- per-lane K decomposition: k = 4 ks + g = 15 f + j
-    int voff[kFmKSteps];   // offset of v[f][n][j] inside a unit slab
-    int joff[kFmKSteps];   // offset of J[e0+n][f] inside the J tile
-    double abig[kFmBigTiles][kFmKSteps];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
-    double asmall[kFmKSteps];              // 4x4x4_4b: block n/4, row 32 + n%4 (row 35 = zero), k = g
+    // ---- per-lane K decomposition: k = 4 ks + g = NFP f + j
+    int voff[G::KS];   // offset of v[f][sub-tile 0 element n][j] inside a unit slab
+    int joff[G::KS];   // offset of J[sub-tile 0 element n][f] inside the J tile
+    double abig[G::BT > 0 ? G::BT : 1][G::KS];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
+    double asmall[G::NS > 0 ? G::NS : 1][G::KS]; // 4x4x4_4b group q: block n/4, row 16 BT + 4q + n%4, k = g
     {
         // R goes through LDS once per block (see stage_operator)
         double* rl = reinterpret_cast<double*>(smem);
-        stage_operator<kFmNf * kNp35 * kFmNfp>(R, rl);
+        stage_operator<G::OP_D>(R, rl);
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < kFmKSteps; ++ks) {
+        for (int ks = 0; ks < G::KS; ++ks) {
             const int k = 4 * ks + g;
-            const int f = k / kFmNfp, j = k - f * kFmNfp;
-            voff[ks] = f * kFmSlabD + n * kFmNfp + j;
-            joff[ks] = jfe ? f * kTE + n : n * kFmNf + f;
+            const int f = k / NFP, j = k - f * NFP;
+            voff[ks] = f * G::SLAB_D + n * NFP + j;
+            joff[ks] = jfe ? f * G::TEL + n : n * kFmNf + f;
 #pragma unroll
-            for (int t = 0; t < kFmBigTiles; ++t) {
+            for (int t = 0; t < G::BT; ++t) {
                 const int i = 16 * t + n;
-                abig[t][ks] = rl[rifj ? (i * kFmNf + f) * kFmNfp + j : (f * kNp35 + i) * kFmNfp + j];
+                abig[t][ks] = rl[rifj ? (i * kFmNf + f) * NFP + j : (f * NP + i) * NFP + j];
             }
-            const int i3 = 32 + (n & 3), i3c = i3 < kNp35 ? i3 : 0;
-            const double a3 = rl[rifj ? (i3c * kFmNf + f) * kFmNfp + j : (f * kNp35 + i3c) * kFmNfp + j];
-            asmall[ks] = (i3 < kNp35) ? a3 : 0.0;
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) {
+                const int i3 = 16 * G::BT + 4 * q + (n & 3), i3c = i3 < NP ? i3 : 0;
+                const double a3 = rl[rifj ? (i3c * kFmNf + f) * NFP + j : (f * NP + i3c) * NFP + j];
+                asmall[q][ks] = (i3 < NP) ? a3 : 0.0;
+            }
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
 
     const unsigned lds_v0 = lds_addr_uniform(L->v[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
-    const int64_t stride = (int64_t)gridDim.x * kFmWavesPerBlock;
-    const int64_t first = (int64_t)blockIdx.x * kFmWavesPerBlock + wave;
+    const int64_t stride = (int64_t)gridDim.x * G::WAVES;
+    const int64_t first = (int64_t)blockIdx.x * G::WAVES + wave;
     if (first >= nTiles) return;
 
     // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<true>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
-    fm_issue_unit_loads<false>(J, P.v[1], E, first, lane, lds_v0 + kFmUnitD * 8, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, false>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
 
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
-    double jv[kFmKSteps];
+    double jv[M][G::KS];
     const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
     int iteration = 0;
     for (int64_t tile = first; tile < nTiles; tile += stride) {
@@ -127,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
             const bool next_is_tile_start = (k + 1 == NB);
             const bool has_next = !next_is_tile_start || (tile + stride < nTiles);
             if (warm && has_next) {
-                if (next_is_tile_start) wait_vmcnt<2 * kFmStoresPerUnit + 10>();
-                else wait_vmcnt<2 * kFmStoresPerUnit + 8>();
+                if (next_is_tile_start) wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS + G::J_INSTR>();
+                else wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -136,16 +158,23 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
 
             if (k == 0) {
 #pragma unroll
-                for (int ks = 0; ks < kFmKSteps; ++ks) jv[ks] = L->j[joff[ks]];
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks)
+                        jv[m][ks] = L->j[joff[ks] + (jfe ? 16 * m : 16 * m * kFmNf)];
             }
             const double* vs = L->v[slot];
-            double bfrag[kFmKSteps];
+            double bfrag[M][G::KS];
 #pragma unroll
-            for (int ks = 0; ks < kFmKSteps; ++ks) bfrag[ks] = jv[ks] * vs[voff[ks]];
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) bfrag[m][ks] = jv[m][ks] * vs[voff[ks] + 16 * m * NFP];
             // make sure the slab (and, at k == 0, the J tile) is in registers before
             // the slot is handed back to the DMA engine
 #pragma unroll
-            for (int ks = 0; ks < kFmKSteps; ++ks) asm volatile("" : "+v"(bfrag[ks]));
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(bfrag[m][ks]));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
             // ---- prefetch unit m+2 into the slot just drained
@@ -154,51 +183,60 @@ __global__ __launch_bounds__(256, 2) void facemass_np35_mfma_kernel(
                 const int64_t tile2 = tile + stride * ((k + 2) / NB);
                 if (tile2 < nTiles) {
                     if (k2 == 0)
-                        fm_issue_unit_loads<true>(J, P.v[k2], E, tile2, lane, lds_v0 + slot * (kFmUnitD * 8), lds_j, jfe);
+                        fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[k2], E, tile2, lane,
+                                                              lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                     else
-                        fm_issue_unit_loads<false>(J, P.v[k2], E, tile2, lane, lds_v0 + slot * (kFmUnitD * 8), lds_j, jfe);
+                        fm_issue_unit_loads<NP, NFP, M, false>(J, P.v[k2], E, tile2, lane,
+                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                 }
             }
 
-            // ---- 30 + 15 MFMAs
-            v4d acc[kFmBigTiles];
-            double acc3 = 0.0;
 #pragma unroll
-            for (int t = 0; t < kFmBigTiles; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int m = 0; m < M; ++m) {
+                // ---- BT x KS big + NS x KS small MFMAs
+                v4d acc[G::BT > 0 ? G::BT : 1];
+                double accs[G::NS > 0 ? G::NS : 1];
 #pragma unroll
-            for (int ks = 0; ks < kFmKSteps; ++ks) {
+                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int t = 0; t < kFmBigTiles; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][ks], bfrag[ks], acc[t], 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(asmall[ks], bfrag[ks], acc3, 0, 0, 0);
-            }
-
-            // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e0 + n][16t + g + 4q];
-            //      4x4x4_4b D: lane (g, n) holds out[e0 + n][32 + g] (g == 3 is padding)
-            double* ob = L->o;
+                for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
 #pragma unroll
-            for (int t = 0; t < kFmBigTiles; ++t)
+                for (int ks = 0; ks < G::KS; ++ks) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ob[n * kNp35 + 16 * t + g + 4 * q] = acc[t][q];
-            if (g < 3) ob[n * kNp35 + 32 + g] = acc3;
-            wave_lds_fence();
-            double* op = P.out[k] + tile * (kTE * kNp35);
+                    for (int t = 0; t < G::BT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][ks], bfrag[m][ks], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                if (c < 4 || lane < 24) {
-                    const int q = c * 64 + lane;
-                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(asmall[q][ks], bfrag[m][ks], accs[q], 0, 0, 0);
                 }
+
+                // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e][16t + g + 4q'];
+                //      4x4x4_4b D of group q: lane (g, n) holds out[e][16 BT + 4q + g]
+                double* ob = L->o;
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) {
+                    const int i = 16 * G::BT + 4 * q + g;
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                }
+                wave_lds_fence();
+                double* op = P.out[k] + (tile * G::TEL + 16 * m) * NP;
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
+                        const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                        __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
+                    }
+                }
+                wave_lds_fence();
             }
-            wave_lds_fence();
             slot ^= 1;
         }
     }
-}
-
-inline bool facemass_mfma_supported(int Np, int nf, int Nfp, int b) {
-    return Np == kNp35 && nf == kFmNf && Nfp == kFmNfp && b >= 2;
 }
 
 }  // namespace fe

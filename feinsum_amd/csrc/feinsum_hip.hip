@@ -118,6 +118,89 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
     return FE_OK;
 }
 
+template <int NP, int M>
+int launch_div(const double* J, const double* D, const double* u, double* out, int64_t E, int dbg,
+               hipStream_t s, int64_t* e_done) {
+    using G = fe::DivGeom<NP, M>;
+    const int64_t nTiles = E / G::TEL;
+    *e_done = nTiles * G::TEL;
+    if (nTiles == 0) return FE_OK;
+    static std::once_flag once;
+    static int attr_rc = FE_OK;
+    std::call_once(once, [] {
+        attr_rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+#ifdef FE_EXPERIMENTS
+        if (NP == 35) {
+            set_max_lds(fe::div3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
+            set_max_lds(fe::div3d_mfma_kernel<NP, M, 2>, G::LDS_BYTES);
+            set_max_lds(fe::div3d_mfma_kernel<NP, M, 3>, G::LDS_BYTES);
+            set_max_lds(fe::div3d_mfma_kernel<NP, M, 8>, G::LDS_BYTES);
+        }
+#endif
+    });
+    if (attr_rc != FE_OK) return attr_rc;
+    const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
+#define FE_DIV_CASE(DBG) \
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles)
+    switch (NP == 35 ? dbg : 0) {
+#ifdef FE_EXPERIMENTS
+        case 1: FE_DIV_CASE(1); break;
+        case 2: FE_DIV_CASE(2); break;
+        case 3: FE_DIV_CASE(3); break;
+        case 8: FE_DIV_CASE(8); break;
+#endif
+        default: FE_DIV_CASE(0); break;
+    }
+#undef FE_DIV_CASE
+    return FE_OK;
+}
+
+template <int NP, int NFP, int M, int NB>
+int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
+                 int jfe, int rifj, hipStream_t s) {
+    using G = fe::FmGeom<NP, NFP, M>;
+    static std::once_flag once;
+    static int attr_rc = FE_OK;
+    std::call_once(once, [] { attr_rc = set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB>), dim3(persistent_grid(nTiles, G::WAVES)),
+                       dim3(256), G::LDS_BYTES, s, J, R, P, E, nTiles, jfe, rifj);
+    return FE_OK;
+}
+
+// One MFMA launch for a group of nb fields (2 <= nb <= kMaxGroup of the geometry).
+template <int NP, int NFP, int M>
+int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, int64_t E, int64_t nTiles,
+              int jfe, int rifj, hipStream_t s) {
+    switch (nb) {
+        case 2: return launch_fm_nb<NP, NFP, M, 2>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 3: return launch_fm_nb<NP, NFP, M, 3>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 4: return launch_fm_nb<NP, NFP, M, 4>(J, R, P, E, nTiles, jfe, rifj, s);
+        default: break;
+    }
+    if constexpr (NP == 35) {   // p = 4, the headline order: groups of up to 8 fields
+        switch (nb) {
+            case 5: return launch_fm_nb<NP, NFP, M, 5>(J, R, P, E, nTiles, jfe, rifj, s);
+            case 6: return launch_fm_nb<NP, NFP, M, 6>(J, R, P, E, nTiles, jfe, rifj, s);
+            case 7: return launch_fm_nb<NP, NFP, M, 7>(J, R, P, E, nTiles, jfe, rifj, s);
+            case 8: return launch_fm_nb<NP, NFP, M, 8>(J, R, P, E, nTiles, jfe, rifj, s);
+            default: break;
+        }
+    }
+    return fail(FE_EINVAL, "face-mass: internal field grouping error (nb=%d)", nb);
+}
+
+struct FmChoice { int max_group, tel; };
+// (Np, Nfp) pairs of tetrahedral orders p = 1..4 with nf = 4
+inline bool fm_mfma_geometry(int Np, int nf, int Nfp, FmChoice* c) {
+    if (nf != fe::kFmNf) return false;
+    if (Np == 35 && Nfp == 15) { *c = {8, 16}; return true; }
+    if (Np == 20 && Nfp == 10) { *c = {4, 16}; return true; }
+    if (Np == 10 && Nfp == 6) { *c = {4, 32}; return true; }
+    if (Np == 4 && Nfp == 3) { *c = {4, 64}; return true; }
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -211,40 +294,20 @@ int fe_div3d_f64(const double* J, const double* D, const double* u, double* out,
         return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool mfma_ok = fe::div_mfma_supported(Np);
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
     if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "div: MFMA variant is compiled for Np == 35 only (Np=%d)", Np);
+        return fail(FE_EUNSUPPORTED, "div: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
     int64_t e_done = 0;
     if (variant != FE_VARIANT_GENERIC && mfma_ok) {
-        const int64_t nTiles = E / fe::kTE;
-        if (nTiles > 0) {
-            static std::once_flag once;
-            static int attr_rc = FE_OK;
-            std::call_once(once, [] {
-                attr_rc = set_max_lds(fe::div3d_np35_mfma_kernel<0>, fe::kDivLdsBytes);
-#ifdef FE_EXPERIMENTS
-                set_max_lds(fe::div3d_np35_mfma_kernel<1>, fe::kDivLdsBytes);
-                set_max_lds(fe::div3d_np35_mfma_kernel<2>, fe::kDivLdsBytes);
-                set_max_lds(fe::div3d_np35_mfma_kernel<3>, fe::kDivLdsBytes);
-                set_max_lds(fe::div3d_np35_mfma_kernel<8>, fe::kDivLdsBytes);
-#endif
-            });
-            if (attr_rc != FE_OK) return attr_rc;
-            const dim3 g(persistent_grid(nTiles, fe::kDivWavesPerBlock)), b(256);
-#define FE_DIV_CASE(DBG) \
-    hipLaunchKernelGGL(fe::div3d_np35_mfma_kernel<DBG>, g, b, fe::kDivLdsBytes, s, J, D, u, out, E, nTiles)
-            switch (variant >= 1000 ? (variant - 1000) & 15 : 0) {
-#ifdef FE_EXPERIMENTS
-                case 1: FE_DIV_CASE(1); break;
-                case 2: FE_DIV_CASE(2); break;
-                case 3: FE_DIV_CASE(3); break;
-                case 8: FE_DIV_CASE(8); break;
-#endif
-                default: FE_DIV_CASE(0); break;
-            }
-#undef FE_DIV_CASE
-            e_done = nTiles * fe::kTE;
+        const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
+        int rc = FE_OK;
+        switch (Np) {   // wave tile = 16 M elements
+            case 35: rc = launch_div<35, 1>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 20: rc = launch_div<20, 1>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 10: rc = launch_div<10, 3>(J, D, u, out, E, dbg, s, &e_done); break;
+            default: rc = launch_div<4, 5>(J, D, u, out, E, dbg, s, &e_done); break;
         }
+        if (rc != FE_OK) return rc;
     }
     if (e_done < E)
         hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
@@ -280,52 +343,39 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
     if (E * (int64_t)Np >= (int64_t)1 << 39) return fail(FE_EINVAL, "E*Np too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    const bool mfma_ok = fe::facemass_mfma_supported(Np, nf, Nfp, b);
+    FmChoice geo{0, 16};
+    const bool mfma_ok = fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2;
     if (variant == FE_VARIANT_MFMA && !mfma_ok)
         return fail(FE_EUNSUPPORTED,
-                    "face-mass: MFMA variant is compiled for Np=35 nf=4 Nfp=15 and b >= 2 only");
+                    "face-mass: MFMA variant is compiled for nf=4, (Np,Nfp) in {(4,3),(10,6),(20,10),(35,15)}, b >= 2");
     const int jfe = (layout_flags & FE_FM_J_FE) ? 1 : 0, rifj = (layout_flags & FE_FM_R_IFJ) ? 1 : 0;
     const int64_t jEs = jfe ? 1 : nf, jFs = jfe ? E : 1;
     const int rF = rifj ? Nfp : Np * Nfp, rI = rifj ? nf * Nfp : Nfp;
     const bool use_mfma = variant != FE_VARIANT_GENERIC && mfma_ok;
-    const int64_t nTiles = use_mfma ? E / fe::kTE : 0;
-    const int64_t e_done = nTiles * fe::kTE;
-    if (nTiles > 0) {
-        static std::once_flag once;
-        static int attr_rc = FE_OK;
-        std::call_once(once, [] {
-#define FE_FM_ATTR(NB) if (attr_rc == FE_OK) attr_rc = set_max_lds(fe::facemass_np35_mfma_kernel<NB>, fe::kFmLdsBytes);
-            FE_FM_ATTR(2) FE_FM_ATTR(3) FE_FM_ATTR(4) FE_FM_ATTR(5) FE_FM_ATTR(6) FE_FM_ATTR(7) FE_FM_ATTR(8)
-#undef FE_FM_ATTR
-        });
-        if (attr_rc != FE_OK) return attr_rc;
-    }
-    // fields go in groups of up to 8 per launch; never leave a group of 1 for the MFMA kernel
+    const int64_t nTiles = use_mfma ? E / geo.tel : 0;      // full wave tiles
+    const int64_t e_done = nTiles * geo.tel;
+    const int max_group = use_mfma ? geo.max_group : fe::kMaxFields;
+    // fields go in groups of up to max_group per launch; never leave a group of 1 for the MFMA kernel
     for (int k0 = 0; k0 < b;) {
-        int nb = (b - k0 < fe::kMaxFields) ? b - k0 : fe::kMaxFields;
-        if (b - k0 - nb == 1) nb -= 1;
+        int nb = (b - k0 < max_group) ? b - k0 : max_group;
+        if (use_mfma && b - k0 - nb == 1) nb -= 1;
         fe::FieldPtrs P;
         for (int k = 0; k < fe::kMaxFields; ++k) {
             P.v[k] = v[k0 + (k < nb ? k : 0)];
             P.out[k] = out[k0 + (k < nb ? k : 0)];
         }
-        const dim3 block(256);
         if (nTiles > 0) {
-            const dim3 grid(persistent_grid(nTiles, fe::kFmWavesPerBlock));
-#define FE_FM_CASE(NB)                                                                             \
-    case NB:                                                                                       \
-        hipLaunchKernelGGL(fe::facemass_np35_mfma_kernel<NB>, grid, block, fe::kFmLdsBytes, s, J,  \
-                           R, P, E, nTiles, jfe, rifj);                                            \
-        break;
-            switch (nb) {
-                FE_FM_CASE(2) FE_FM_CASE(3) FE_FM_CASE(4) FE_FM_CASE(5)
-                FE_FM_CASE(6) FE_FM_CASE(7) FE_FM_CASE(8)
-                default: return fail(FE_EINVAL, "face-mass: internal field grouping error");
+            int rc = FE_OK;
+            switch (Np) {   // wave tile = 16 M elements
+                case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                case 20: rc = launch_fm<20, 10, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                case 10: rc = launch_fm<10, 6, 2>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                default: rc = launch_fm<4, 3, 4>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
             }
-#undef FE_FM_CASE
+            if (rc != FE_OK) return rc;
         }
         if (e_done < E) {
-            const dim3 grid(generic_grid(E - e_done, Np));
+            const dim3 grid(generic_grid(E - e_done, Np)), block(256);
 #define FE_FM_CASE(NB)                                                                             \
     case NB:                                                                                       \
         hipLaunchKernelGGL(fe::facemass_generic_kernel<NB>, grid, block, 0, s, J, R, P, E, Np, nf, \

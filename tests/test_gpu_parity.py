@@ -96,6 +96,27 @@ def test_grad_lower_orders_mfma(torch_cuda, Np, E):
     _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
 
 
+@pytest.mark.parametrize("Np", [4, 10, 20])
+@pytest.mark.parametrize("E", [15, 16, 79, 80, 81, 1000, 10007])
+def test_div_lower_orders_mfma(torch_cuda, Np, E):
+    expr = dg.div(Np)
+    host = generate_host_input_arrays(expr, E, np_seed=2 * Np + E)
+    ref = _oracle(expr, host)
+    _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
+    _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
+
+
+@pytest.mark.parametrize("order", [(4, 3), (10, 6), (20, 10)])
+@pytest.mark.parametrize("E", [15, 16, 63, 64, 65, 1000, 4099])
+@pytest.mark.parametrize("b", [2, 4, 5, 7])
+def test_face_mass_lower_orders_mfma(torch_cuda, order, E, b):
+    # p = 1, 2, 3 tetrahedra: (Np, Nfp) = (4, 3), (10, 6), (20, 10); fields grouped by up to 4
+    Np, Nfp = order
+    for expr in (dg.face_mass(b, Np=Np, Nfp=Nfp), dg.face_mass_ifj_fe(b, Np=Np, Nfp=Nfp)):
+        host = generate_host_input_arrays(expr, E, np_seed=Np + E + b)
+        _assert_close(_run(torch_cuda, expr, host, transform="mfma"), _oracle(expr, host))
+
+
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
 def test_face_mass_field_counts(torch_cuda, b):
     # b = 1 (generic only), odd counts, > 8 fields (several launches), 19 as in the archive

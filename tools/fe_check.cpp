@@ -59,7 +59,8 @@ static int ab_main(int argc, char** argv) {
     const int rounds = atoi(argv[4]), launches = atoi(argv[5]);
     std::vector<int> variants;
     for (char* tok = strtok(argv[6], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
-    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4,
+              Nfp = Np == 35 ? 15 : Np == 20 ? 10 : Np == 10 ? 6 : Np == 4 ? 3 : 15, b = 4;
     fe_argpack a;
     memset(&a, 0, sizeof a);
     a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
@@ -154,7 +155,8 @@ static int abl_main(int argc, char** argv) {
         fns.push_back((time_fn)dlsym(h, "fe_time_launches"));
         names.push_back(argv[i]);
     }
-    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4,
+              Nfp = Np == 35 ? 15 : Np == 20 ? 10 : Np == 10 ? 6 : Np == 4 ? 3 : 15, b = 4;
     fe_argpack a;
     memset(&a, 0, sizeof a);
     a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b;
@@ -204,7 +206,8 @@ int main(int argc, char** argv) {
     const int variant = argc > 3 ? atoi(argv[3]) : 0;
     const int launches = argc > 4 ? atoi(argv[4]) : 20;
     const int check = argc > 5 ? atoi(argv[5]) : 1;
-    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4, Nfp = 15, b = 4;
+    const int Np = getenv("FE_NP") ? atoi(getenv("FE_NP")) : 35, nf = 4,
+              Nfp = Np == 35 ? 15 : Np == 20 ? 10 : Np == 10 ? 6 : Np == 4 ? 3 : 15, b = 4;
 
     char name[256];
     double pf, pb;
