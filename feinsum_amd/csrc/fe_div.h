@@ -60,7 +60,7 @@ struct DivGeom {
 template <int NP, int M, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int64_t nTiles) {
+    double* __restrict__ out, int64_t E, int64_t nTiles, int opT) {
     using G = DivGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,12 +85,13 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t)
-                    abig[t][jq][r] = (j < NP) ? dl[(r * NP + 16 * t + n) * NP + j] : 0.0;
+                    abig[t][jq][r] = (j < NP) ? dl[opT ? (r * NP + j) * NP + 16 * t + n   // opT: D stored [r][j][i]
+                                                       : (r * NP + 16 * t + n) * NP + j] : 0.0;
         }
         for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
             const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
             const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / 3) + gg, r = ks % 3;
-            asmall[idx] = (j < NP && i < NP) ? dl[(r * NP + i) * NP + j] : 0.0;
+            asmall[idx] = (j < NP && i < NP) ? dl[opT ? (r * NP + j) * NP + i : (r * NP + i) * NP + j] : 0.0;
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }

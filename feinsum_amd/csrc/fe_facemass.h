@@ -85,7 +85,7 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 template <int NP, int NFP, int M, int NB>
 __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
-    int64_t nTiles, int jfe, int rifj) {
+    int64_t nTiles, int jfe, int rlayout) {
     using G = FmGeom<NP, NFP, M>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
         double* rl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D>(R, rl);
         __syncthreads();
+        // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i]
+        auto ridx = [&](int f, int i, int j) {
+            return rlayout == 0 ? (f * NP + i) * NFP + j
+                 : rlayout == 1 ? (i * kFmNf + f) * NFP + j
+                 : rlayout == 2 ? (f * NFP + j) * NP + i
+                                : (j * kFmNf + f) * NP + i;
+        };
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
             const int k = 4 * ks + g;
@@ -114,12 +121,12 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
 #pragma unroll
             for (int t = 0; t < G::BT; ++t) {
                 const int i = 16 * t + n;
-                abig[t][ks] = rl[rifj ? (i * kFmNf + f) * NFP + j : (f * NP + i) * NFP + j];
+                abig[t][ks] = rl[ridx(f, i, j)];
             }
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) {
                 const int i3 = 16 * G::BT + 4 * q + (n & 3), i3c = i3 < NP ? i3 : 0;
-                const double a3 = rl[rifj ? (i3c * kFmNf + f) * NFP + j : (f * NP + i3c) * NFP + j];
+                const double a3 = rl[ridx(f, i3c, j)];
                 asmall[q][ks] = (i3 < NP) ? a3 : 0.0;
             }
         }

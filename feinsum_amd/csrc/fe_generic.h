@@ -11,7 +11,7 @@ namespace fe {
 // div: out[e,i] = sum_{x,r,j} J[x,r,e] D[r,i,j] u[x,e,j]
 __global__ __launch_bounds__(256) void div3d_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin) {
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (E - e_begin) * Np) return;
     const int64_t e = e_begin + idx / Np;
@@ -22,16 +22,17 @@ __global__ __launch_bounds__(256) void div3d_generic_kernel(
     const double* u0 = u + ((int64_t)0 * E + e) * Np;
     const double* u1 = u + ((int64_t)1 * E + e) * Np;
     const double* u2 = u + ((int64_t)2 * E + e) * Np;
-    const double* d0 = D + (int64_t)(0 * Np + i) * Np;
-    const double* d1 = D + (int64_t)(1 * Np + i) * Np;
-    const double* d2 = D + (int64_t)(2 * Np + i) * Np;
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;   // opT: D stored as [r][j][i]
+    const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
+    const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
+    const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
     double acc = 0.0;
     for (int j = 0; j < Np; ++j) {
         const double a = u0[j], b = u1[j], c = u2[j];
         const double ju0 = jac[0] * a + jac[3] * b + jac[6] * c;  // r = 0: sum_x J[x,0,e] u[x,e,j]
         const double ju1 = jac[1] * a + jac[4] * b + jac[7] * c;
         const double ju2 = jac[2] * a + jac[5] * b + jac[8] * c;
-        acc += d0[j] * ju0 + d1[j] * ju1 + d2[j] * ju2;
+        acc += d0[j * sj] * ju0 + d1[j * sj] * ju1 + d2[j * sj] * ju2;
     }
     out[e * Np + i] = acc;
 }
@@ -43,11 +44,11 @@ struct FieldPtrs {
 };
 
 // face-mass: out_k[e,i] = sum_{f,j} J[e,f] R[f,i,j] v_k[f,e,j]
-//   jEs / jFs : strides of J along e and f;  rF / rI : strides of R along f and i
+//   jEs / jFs : strides of J along e and f;  rF / rI / rJ : strides of R along f, i and j
 template <int NB>
 __global__ __launch_bounds__(256) void facemass_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int Np,
-    int nf, int Nfp, int64_t jEs, int64_t jFs, int rF, int rI, int64_t e_begin) {
+    int nf, int Nfp, int64_t jEs, int64_t jFs, int rF, int rI, int rJ, int64_t e_begin) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (E - e_begin) * Np) return;
     const int64_t e = e_begin + idx / Np;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void facemass_generic_kernel(
         const double* rr = R + (int64_t)f * rF + (int64_t)i * rI;
         const int64_t vo = ((int64_t)f * E + e) * Nfp;
         for (int j = 0; j < Nfp; ++j) {
-            const double w = rr[j] * jf;
+            const double w = rr[j * rJ] * jf;
 #pragma unroll
             for (int k = 0; k < NB; ++k) acc[k] += w * P.v[k][vo + j];
         }

@@ -114,7 +114,7 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 template <int NP, int M, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int64_t nTiles) {
+    double* __restrict__ out, int64_t E, int64_t nTiles, int opT) {
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
             for (int ks = 0; ks < G::KS; ++ks) {
                 const int j = 4 * ks + g;
                 const bool ok = (s < 3 * G::TG) && (i < NP) && (j < NP);
-                afrag[t][ks] = ok ? dl[(r * NP + (i < NP ? i : 0)) * NP + (j < NP ? j : 0)] : 0.0;
+                const int ic = i < NP ? i : 0, jc = j < NP ? j : 0;   // opT: D stored as [r][j][i]
+                afrag[t][ks] = ok ? dl[opT ? (r * NP + jc) * NP + ic : (r * NP + ic) * NP + jc] : 0.0;
             }
         }
         __syncthreads();
@@ -260,21 +261,22 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
 // the device and the path for shapes the MFMA kernel is not compiled for.
 __global__ __launch_bounds__(256) void grad3d_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin) {
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (E - e_begin) * Np) return;
     const int64_t e = e_begin + idx / Np;
     const int i = (int)(idx % Np);
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     const double* ue = u + e * Np;
-    const double* d0 = D + (int64_t)(0 * Np + i) * Np;
-    const double* d1 = D + (int64_t)(1 * Np + i) * Np;
-    const double* d2 = D + (int64_t)(2 * Np + i) * Np;
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;   // opT: D stored as [r][j][i]
+    const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
+    const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
+    const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
     for (int j = 0; j < Np; ++j) {
         const double uj = ue[j];
-        t0 += d0[j] * uj;
-        t1 += d1[j] * uj;
-        t2 += d2[j] * uj;
+        t0 += d0[j * sj] * uj;
+        t1 += d1[j * sj] * uj;
+        t2 += d2[j * sj] * uj;
     }
     for (int x = 0; x < 3; ++x)
         out[((int64_t)x * E + e) * Np + i] =

@@ -81,7 +81,7 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
 
 template <int NP, int M>
 int launch_grad(const double* J, const double* D, const double* u, double* out, int64_t E,
-                int dbg, hipStream_t s, int64_t* e_done) {
+                int dbg, int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::GradGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles * G::TEL;
@@ -103,7 +103,7 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles)
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
@@ -120,7 +120,7 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
 
 template <int NP, int M>
 int launch_div(const double* J, const double* D, const double* u, double* out, int64_t E, int dbg,
-               hipStream_t s, int64_t* e_done) {
+               int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles * G::TEL;
@@ -141,7 +141,7 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_DIV_CASE(DBG) \
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles)
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_DIV_CASE(1); break;
@@ -249,7 +249,14 @@ int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp
 
 int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
                   int32_t Np, int32_t variant, void* stream) {
+    return fe_grad3d_f64_ex(J, D, u, out, E, Np, 0, variant, stream);
+}
+
+int fe_grad3d_f64_ex(const double* J, const double* D, const double* u, double* out, int64_t E,
+                     int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
     if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad: bad operator flags %d", op_flags);
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
     if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
 #else
@@ -269,23 +276,30 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_grad<35, 1>(J, D, u, out, E, dbg, s, &e_done); break;
-            case 20: rc = launch_grad<20, 2>(J, D, u, out, E, dbg, s, &e_done); break;
-            case 10: rc = launch_grad<10, 3>(J, D, u, out, E, dbg, s, &e_done); break;
-            default: rc = launch_grad<4, 5>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 35: rc = launch_grad<35, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_grad<20, 2>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_grad<10, 3>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_grad<4, 5>(J, D, u, out, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
     if (e_done < E)
         hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
-                           J, D, u, out, E, Np, e_done);
+                           J, D, u, out, E, Np, e_done, opT);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
 
 int fe_div3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
                  int32_t Np, int32_t variant, void* stream) {
+    return fe_div3d_f64_ex(J, D, u, out, E, Np, 0, variant, stream);
+}
+
+int fe_div3d_f64_ex(const double* J, const double* D, const double* u, double* out, int64_t E,
+                    int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
     if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "div: bad operator flags %d", op_flags);
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
     if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
 #else
@@ -302,16 +316,16 @@ int fe_div3d_f64(const double* J, const double* D, const double* u, double* out,
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_div<35, 1>(J, D, u, out, E, dbg, s, &e_done); break;
-            case 20: rc = launch_div<20, 1>(J, D, u, out, E, dbg, s, &e_done); break;
-            case 10: rc = launch_div<10, 3>(J, D, u, out, E, dbg, s, &e_done); break;
-            default: rc = launch_div<4, 5>(J, D, u, out, E, dbg, s, &e_done); break;
+            case 35: rc = launch_div<35, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_div<20, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_div<10, 3>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_div<4, 5>(J, D, u, out, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
     if (e_done < E)
         hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
-                           J, D, u, out, E, Np, e_done);
+                           J, D, u, out, E, Np, e_done, opT);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
@@ -332,7 +346,7 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
     if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
         return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
                     Nfp, b);
-    if (layout_flags & ~3) return fail(FE_EINVAL, "face-mass: bad layout flags %d", layout_flags);
+    if (layout_flags & ~7) return fail(FE_EINVAL, "face-mass: bad layout flags %d", layout_flags);
     if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
         return fail(FE_EUNSUPPORTED, "face-mass: unknown variant %d", variant);
     if (!v || !out) return fail(FE_EINVAL, "face-mass: null pointer table");
@@ -348,9 +362,13 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
     if (variant == FE_VARIANT_MFMA && !mfma_ok)
         return fail(FE_EUNSUPPORTED,
                     "face-mass: MFMA variant is compiled for nf=4, (Np,Nfp) in {(4,3),(10,6),(20,10),(35,15)}, b >= 2");
-    const int jfe = (layout_flags & FE_FM_J_FE) ? 1 : 0, rifj = (layout_flags & FE_FM_R_IFJ) ? 1 : 0;
+    const int jfe = (layout_flags & FE_FM_J_FE) ? 1 : 0;
+    // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i]
+    const int rifj = ((layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((layout_flags & FE_FM_R_T) ? 2 : 0);
     const int64_t jEs = jfe ? 1 : nf, jFs = jfe ? E : 1;
-    const int rF = rifj ? Nfp : Np * Nfp, rI = rifj ? nf * Nfp : Nfp;
+    const int rF = rifj == 0 ? Np * Nfp : rifj == 1 ? Nfp : rifj == 2 ? Nfp * Np : Np;
+    const int rI = rifj == 0 ? Nfp : rifj == 1 ? nf * Nfp : 1;
+    const int rJ = rifj == 0 || rifj == 1 ? 1 : rifj == 2 ? Np : nf * Np;
     const bool use_mfma = variant != FE_VARIANT_GENERIC && mfma_ok;
     const int64_t nTiles = use_mfma ? E / geo.tel : 0;      // full wave tiles
     const int64_t e_done = nTiles * geo.tel;
@@ -379,7 +397,7 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
 #define FE_FM_CASE(NB)                                                                             \
     case NB:                                                                                       \
         hipLaunchKernelGGL(fe::facemass_generic_kernel<NB>, grid, block, 0, s, J, R, P, E, Np, nf, \
-                           Nfp, jEs, jFs, rF, rI, e_done);                                         \
+                           Nfp, jEs, jFs, rF, rI, rJ, e_done);                                     \
         break;
             switch (nb) {
                 FE_FM_CASE(1) FE_FM_CASE(2) FE_FM_CASE(3) FE_FM_CASE(4)
@@ -448,9 +466,9 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
 static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
     switch (family) {
         case FE_FAMILY_GRAD:
-            return fe_grad3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->variant, stream);
+            return fe_grad3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_DIV:
-            return fe_div3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->variant, stream);
+            return fe_div3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_GRADDIV:
             return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
                                     a->variant, stream);

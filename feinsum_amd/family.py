@@ -11,8 +11,10 @@ memory layout and must match the template exactly.
 
 Families (SURVEY §8a): grad ``xre,rij,ej->xei``; div ``xre,rij,xej->ei``;
 face-mass ``ef,fij,fej->ei`` with its layout siblings (J as ``fe``, operator as
-``ifj`` -- ``tuning/impls/ifj_fe_fej_to_ei.py:46-60``).  Anything else is
-evaluated by the generic einsum kernel.
+``ifj`` -- ``tuning/impls/ifj_fe_fej_to_ei.py:46-60``), and the transposed-operator
+siblings of all three (``rji``: ``tuning/impls/xre_rji_xej_to_ei_v1.py``; ``fji`` /
+``jfi``: ``tuning/impls/jfi_fe_fej_to_ei.py:46-56``).  Anything else is evaluated by
+the generic einsum kernel.
 """
 
 from __future__ import annotations
@@ -26,16 +28,19 @@ import numpy as np
 from feinsum_amd.einsum import BatchedEinsum, SizeParam
 
 FAMILY_GRAD, FAMILY_DIV, FAMILY_GRADDIV, FAMILY_FACEMASS = 1, 2, 3, 4
-FM_J_FE, FM_R_IFJ = 1, 2
+FM_J_FE, FM_R_IFJ, FM_R_T = 1, 2, 4
+OP_TRANSPOSED = 1
 
 # (family, layout_flags, subscripts, roles of the operands in template order)
 _TEMPLATES = (
     (FAMILY_GRAD, 0, "xre,rij,ej->xei", ("J", "D", "u")),
+    (FAMILY_GRAD, OP_TRANSPOSED, "xre,rji,ej->xei", ("J", "D", "u")),
     (FAMILY_DIV, 0, "xre,rij,xej->ei", ("J", "D", "u")),
-    (FAMILY_FACEMASS, 0, "ef,fij,fej->ei", ("J", "R", "v")),
-    (FAMILY_FACEMASS, FM_J_FE, "fe,fij,fej->ei", ("J", "R", "v")),
-    (FAMILY_FACEMASS, FM_R_IFJ, "ef,ifj,fej->ei", ("J", "R", "v")),
-    (FAMILY_FACEMASS, FM_J_FE | FM_R_IFJ, "fe,ifj,fej->ei", ("J", "R", "v")),
+    (FAMILY_DIV, OP_TRANSPOSED, "xre,rji,xej->ei", ("J", "D", "u")),     # xre_rji_xej_to_ei_v{0,1}.py
+) + tuple(
+    (FAMILY_FACEMASS, jflag | rflag, f"{jsub},{rsub},fej->ei", ("J", "R", "v"))
+    for jflag, jsub in ((0, "ef"), (FM_J_FE, "fe"))
+    for rflag, rsub in ((0, "fij"), (FM_R_IFJ, "ifj"), (FM_R_T, "fji"), (FM_R_IFJ | FM_R_T, "jfi"))  # jfi_fe_fej_to_ei.py
 )
 
 

@@ -232,6 +232,7 @@ class _FamilyLaunch:
                 pack.u = arg_dict[row[role["u"]].name].data_ptr()
                 pack.out = out.data_ptr()
                 pack.E, pack.Np, pack.variant = self.E, p["Np"], self.variant
+                pack.layout_flags = plan.layout_flags      # FE_OP_* for grad / div
                 self.groups.append(pack)
         else:
             # consecutive rows sharing J and R become one multi-field launch
@@ -259,11 +260,11 @@ class _FamilyLaunch:
         lib = _hip.load_library()
         for pack in self.groups:
             if self.plan.family == FAMILY_GRAD:
-                _hip.check(lib.fe_grad3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
-                                             pack.variant, stream_ptr))
+                _hip.check(lib.fe_grad3d_f64_ex(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
+                                                pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIV:
-                _hip.check(lib.fe_div3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
-                                            pack.variant, stream_ptr))
+                _hip.check(lib.fe_div3d_f64_ex(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
+                                               pack.layout_flags, pack.variant, stream_ptr))
             else:
                 _hip.check(lib.fe_facemass_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                pack.nf, pack.Nfp, pack.b, pack.layout_flags,

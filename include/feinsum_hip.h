@@ -65,6 +65,13 @@ extern "C" {
 #define FE_FM_J_FE   1  /* J[nf][E]      (tuning/impls/ifj_fe_fej_to_ei.py)  */
 #define FE_FM_R_FIJ  0  /* R[nf][Np][Nfp]                                    */
 #define FE_FM_R_IFJ  2  /* L[Np][nf][Nfp]                                    */
+#define FE_FM_R_T    4  /* last two operator axes swapped: R[nf][Nfp][Np], or
+                           with FE_FM_R_IFJ  L[Nfp][nf][Np]  ('jfi',
+                           tuning/impls/jfi_fe_fej_to_ei.py:46-56)           */
+
+/* operator flags for the _ex entry points of grad / div */
+#define FE_OP_TRANSPOSED 1 /* D stored [3][Np(j)][Np(i)]: 'xre,rji,ej->xei',
+                              'xre,rji,xej->ei' (tuning/impls/xre_rji_xej_to_ei_v1.py) */
 
 /* ABI version: major*1000 + minor. */
 int fe_version(void);
@@ -86,6 +93,14 @@ int fe_device_info(int dev, char* name, size_t name_len,
 int fe_grad3d_f64(const double* J, const double* D, const double* u,
                   double* out, int64_t E, int32_t Np, int32_t variant,
                   void* stream);
+
+/* grad / div with operator flags (FE_OP_*); flags == 0 is fe_grad3d_f64 / fe_div3d_f64. */
+int fe_grad3d_f64_ex(const double* J, const double* D, const double* u,
+                     double* out, int64_t E, int32_t Np, int32_t op_flags,
+                     int32_t variant, void* stream);
+int fe_div3d_f64_ex(const double* J, const double* D, const double* u,
+                    double* out, int64_t E, int32_t Np, int32_t op_flags,
+                    int32_t variant, void* stream);
 
 /* div:   out[e,i] = sum_{x,r,j} J[x,r,e] * D[r,i,j] * u[x,e,j]
  * 'xre,rij,xej->ei' (tuning/impls/xre_rij_xej_to_ei.py:26-60).
@@ -129,7 +144,7 @@ typedef struct fe_argpack {
     const double* const* v;   /* face-mass inputs  (host array of b ptrs)     */
     double* const* outs;      /* face-mass outputs (host array of b ptrs)     */
     int64_t E;
-    int32_t Np, nf, Nfp, b, layout_flags, variant;
+    int32_t Np, nf, Nfp, b, layout_flags, variant;   /* layout_flags: FE_FM_* or FE_OP_* by family */
 } fe_argpack;
 
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed

@@ -47,3 +47,30 @@ GOLDEN_CASES = {
     "batched_div_p4": batched_div_components,
     "grad_p2": lambda: grad(10),
 }
+
+
+def grad_t(Np=NP):
+    # transposed operator sibling, D stored [r][j][i]
+    return f.einsum("xre,rji,ej->xei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)),
+                    f.array("u", ("E", Np)))
+
+
+def div_t(Np=NP):
+    # tuning/impls/xre_rji_xej_to_ei_v1.py
+    return f.einsum("xre,rji,xej->ei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)),
+                    f.array("u", (3, "E", Np)))
+
+
+def face_mass_jfi_fe(b=4, Np=NP, nf=NF, Nfp=NFP):
+    # tuning/impls/jfi_fe_fej_to_ei.py:46-56
+    return f.batched_einsum(
+        "jfi,fe,fej->ei",
+        [[f.array("L", (Nfp, nf, Np)), f.array("J", (nf, "E")), f.array(f"v{i}", (nf, "E", Nfp))]
+         for i in range(b)])
+
+
+def face_mass_fji(b=4, Np=NP, nf=NF, Nfp=NFP):
+    return f.batched_einsum(
+        "ef,fji,fej->ei",
+        [[f.array("J", ("E", nf)), f.array("R", (nf, Nfp, Np)), f.array(f"v{i}", (nf, "E", Nfp))]
+         for i in range(b)])

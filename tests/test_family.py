@@ -6,7 +6,8 @@ import random
 import string
 
 import feinsum_amd as f
-from feinsum_amd.family import FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD, FM_J_FE, FM_R_IFJ
+from feinsum_amd.family import (FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD, FM_J_FE, FM_R_IFJ, FM_R_T,
+                                OP_TRANSPOSED)
 
 import dg
 
@@ -70,3 +71,16 @@ def test_all_operand_orders_div():
         p = f.match_family(f.einsum(subs, *[ops[k][1] for k in order]))
         assert p is not None and p.family == FAMILY_DIV
         assert order[p.roles["J"]] == 0 and order[p.roles["D"]] == 1 and order[p.roles["u"]] == 2
+
+
+def test_transposed_operator_siblings():
+    p = f.match_family(dg.grad_t())
+    assert p.family == FAMILY_GRAD and p.layout_flags == OP_TRANSPOSED
+    p = f.match_family(dg.div_t())
+    assert p.family == FAMILY_DIV and p.layout_flags == OP_TRANSPOSED
+    assert f.match_family(dg.grad()).layout_flags == 0 and f.match_family(dg.div()).layout_flags == 0
+    p = f.match_family(dg.face_mass_jfi_fe())
+    assert p.family == FAMILY_FACEMASS and p.layout_flags == (FM_J_FE | FM_R_IFJ | FM_R_T)
+    assert p.roles == {"J": 1, "R": 0, "v": 2} and p.params == {"Np": 35, "nf": 4, "Nfp": 15}
+    p = f.match_family(dg.face_mass_fji())
+    assert p.family == FAMILY_FACEMASS and p.layout_flags == FM_R_T

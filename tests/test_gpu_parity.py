@@ -61,7 +61,10 @@ def test_golden_vectors(torch_cuda, golden_dir, name, E):
 
 
 FAMILIES = {"grad": dg.grad, "div": dg.div, "face_mass": dg.face_mass,
-            "face_mass_ifj_fe": dg.face_mass_ifj_fe}
+            "face_mass_ifj_fe": dg.face_mass_ifj_fe,
+            # transposed-operator siblings
+            "grad_t": dg.grad_t, "div_t": dg.div_t, "face_mass_jfi_fe": dg.face_mass_jfi_fe,
+            "face_mass_fji": dg.face_mass_fji}
 
 
 @pytest.mark.parametrize("fam", sorted(FAMILIES))
@@ -115,6 +118,17 @@ def test_face_mass_lower_orders_mfma(torch_cuda, order, E, b):
     for expr in (dg.face_mass(b, Np=Np, Nfp=Nfp), dg.face_mass_ifj_fe(b, Np=Np, Nfp=Nfp)):
         host = generate_host_input_arrays(expr, E, np_seed=Np + E + b)
         _assert_close(_run(torch_cuda, expr, host, transform="mfma"), _oracle(expr, host))
+
+
+@pytest.mark.parametrize("Np", [4, 10, 20])
+def test_transposed_operators_lower_orders(torch_cuda, Np):
+    Nfp = {4: 3, 10: 6, 20: 10}[Np]
+    for expr in (dg.grad_t(Np), dg.div_t(Np), dg.face_mass_jfi_fe(4, Np=Np, Nfp=Nfp),
+                 dg.face_mass_fji(3, Np=Np, Nfp=Nfp)):
+        host = generate_host_input_arrays(expr, 1003, np_seed=Np)
+        ref = _oracle(expr, host)
+        _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
+        _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
 
 
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
