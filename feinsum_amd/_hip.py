@@ -24,7 +24,8 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MF
 #: every symbol declared in include/feinsum_hip.h (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
-    "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_graddiv3d_f64",
+    "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
+    "fe_graddiv3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
 )
@@ -99,7 +100,7 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
-    for name in ("fe_grad3d_f64_ex", "fe_div3d_f64_ex"):
+    for name in ("fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64"):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -160,6 +161,7 @@ def _ptr_array(ptrs: Sequence[int]):
 
 
 OP_TRANSPOSED = 1   # FE_OP_TRANSPOSED: operator stored [3][Np(j)][Np(i)]
+OP_J_ES = 2         # FE_OP_J_ES: div component, J stored [E][3]
 
 
 def grad3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0,
@@ -170,6 +172,11 @@ def grad3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stre
 def div3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0,
           op_flags: int = 0) -> None:
     check(load_library().fe_div3d_f64_ex(J, D, u, out, E, Np, op_flags, variant_code(variant), stream))
+
+
+def divcomp3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0,
+              op_flags: int = 0) -> None:
+    check(load_library().fe_divcomp3d_f64(J, D, u, out, E, Np, op_flags, variant_code(variant), stream))
 
 
 def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: int, E: int,

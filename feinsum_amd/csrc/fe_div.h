@@ -20,6 +20,10 @@
 //   Np 35: BT 2 + 1 group (rows 32-34);  20: BT 1 + 1 group;  10: 3 groups;  4: 1 group.
 // K is ordered (jq, r) with j = 4 jq + g: one group of three u values (x = 0..2)
 // feeds three consecutive k-steps.
+// MODE 1 ("component", 'se,sij,ej->ei': out[e,i] = sum_{s,j} J[s,e] D[s,i,j] u[e,j], the einsum
+// of test/test_codegen.py:34-66 and tuning/impls/re_rij_ej_to_ei.py) shares everything but the
+// B fragment, which is the single multiply J[s,e] * u[e,j] from ONE u plane and three J rows
+// (J stored [3][E], or [E][3] as in examples/dg_wave_div.py 'es,sij,ej->ei').
 // Data movement as in fe_grad.h; a wave tile is 16 M elements.  The three u planes of a tile
 // leave no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a tile are
 // computed up front, which frees the u buffer, and the next tile's loads are issued before
@@ -29,9 +33,11 @@
 
 namespace fe {
 
-template <int NP, int M>
+template <int NP, int M, int MODE = 0>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
+    static constexpr int NPLANES = MODE ? 1 : 3;        // u planes per tile
+    static constexpr int NJ = MODE ? 3 : 9;             // J values per element
     static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = 3 KSJ, ordered (jq, r)
     static constexpr int BT = NP / 16;                  // 16-row tiles
     static constexpr int NR = NP - 16 * BT;             // rows left for the 4x4x4 groups
@@ -39,13 +45,13 @@ struct DivGeom {
     static constexpr int PLANE_D = TEL * NP;            // doubles: one u plane of a tile / the out tile
     static constexpr int SUB_D = 16 * NP;
     static constexpr int P_CHUNKS = PLANE_D / 2, P_INSTR = (P_CHUNKS + 63) / 64;
-    static constexpr int J_ROW_CHUNKS = TEL / 2, J_CHUNKS = 9 * J_ROW_CHUNKS, J_INSTR = (J_CHUNKS + 63) / 64;
+    static constexpr int J_ROW_CHUNKS = TEL / 2, J_CHUNKS = NJ * J_ROW_CHUNKS, J_INSTR = (J_CHUNKS + 63) / 64;
     static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
-    static constexpr int LOADS = 3 * P_INSTR + J_INSTR, STORES = M * SUB_INSTR;
+    static constexpr int LOADS = NPLANES * P_INSTR + J_INSTR, STORES = M * SUB_INSTR;
     struct WaveLds {
-        double u[3][PLANE_D];     // u[x][e0 .. e0+TEL-1][0..Np-1]
-        double o[SUB_D];          // output transposition buffer (one 16-element sub-tile)
-        double j[9 * TEL];        // J[x*3+r][e0 + 0..TEL-1]
+        double u[NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
+        double o[SUB_D];              // output transposition buffer (one 16-element sub-tile)
+        double j[NJ * TEL];           // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s])
     };
     static constexpr int WAVES = 4;
     static constexpr int ASMALL_D = 3 * KSJ * NS * 16;  // [k-step][group][g][row] doubles, per block
@@ -57,11 +63,11 @@ struct DivGeom {
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int NP, int M, int kDbg = 0>
+template <int NP, int M, int kDbg = 0, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int64_t nTiles, int opT) {
-    using G = DivGeom<NP, M>;
+    double* __restrict__ out, int64_t E, int64_t nTiles, int opT, int jes) {
+    using G = DivGeom<NP, M, MODE>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
         const int64_t e0 = tile * G::TEL;
         const char* ub = reinterpret_cast<const char*>(u) + e0 * (NP * 8) + lane * 16;
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
+        for (int x = 0; x < G::NPLANES; ++x) {
             const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
             for (int c = 0; c < G::P_INSTR; ++c)
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
         for (int c = 0; c < G::J_INSTR; ++c) {
             const int q = c * 64 + lane;
             const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
-            if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS)
-                glds16(jb + ((int64_t)row * E) * 8 + col * 16, lds_j + c * 1024);
+            // rows of E doubles; MODE 1 with J stored [E][3]: one contiguous span of 3 TEL doubles
+            const char* src = (MODE && jes) ? jb + e0 * 16 + q * 16 : jb + ((int64_t)row * E) * 8 + col * 16;
+            if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     };
     int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
@@ -137,20 +144,23 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
         double bfrag[M][G::KSJ][3];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            double jac[9];
+            double jac[G::NJ];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + 16 * m + n];   // jac[x*3 + r]
+            for (int k = 0; k < G::NJ; ++k)   // jac[x*3 + r]  (MODE 1: jac[s])
+                jac[k] = (MODE && jes) ? L->j[(16 * m + n) * 3 + k] : L->j[k * G::TEL + 16 * m + n];
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
                 const int j = 4 * jq + g;
                 const int jc = j < NP ? j : 0;
                 double u0 = L->u[0][(16 * m + n) * NP + jc];
-                double u1 = L->u[1][(16 * m + n) * NP + jc];
-                double u2 = L->u[2][(16 * m + n) * NP + jc];
+                double u1 = L->u[MODE ? 0 : 1][(16 * m + n) * NP + jc];
+                double u2 = L->u[MODE ? 0 : 2][(16 * m + n) * NP + jc];
                 if (j >= NP) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
-                    bfrag[m][jq][r] = jac[0 * 3 + r] * u0 + jac[1 * 3 + r] * u1 + jac[2 * 3 + r] * u2;
+                    bfrag[m][jq][r] = MODE ? jac[r] * u0
+                                           : jac[0 * 3 + r] * u0 + jac[(MODE ? 0 : 1) * 3 + r] * u1 +
+                                                 jac[(MODE ? 0 : 2) * 3 + r] * u2;
             }
         }
         // the u / J tiles are now in registers: hand the buffers back to the DMA engine

@@ -37,6 +37,28 @@ __global__ __launch_bounds__(256) void div3d_generic_kernel(
     out[e * Np + i] = acc;
 }
 
+// div component: out[e,i] = sum_{s,j} J[s,e] D[s,i,j] u[e,j]   ('se,sij,ej->ei')
+__global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT, int jes) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (E - e_begin) * Np) return;
+    const int64_t e = e_begin + idx / Np;
+    const int i = (int)(idx % Np);
+    const double j0 = jes ? J[e * 3 + 0] : J[0 * E + e];
+    const double j1 = jes ? J[e * 3 + 1] : J[1 * E + e];
+    const double j2 = jes ? J[e * 3 + 2] : J[2 * E + e];
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+    const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
+    const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
+    const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
+    const double* ue = u + e * Np;
+    double acc = 0.0;
+    for (int j = 0; j < Np; ++j)
+        acc += (d0[j * sj] * j0 + d1[j * sj] * j1 + d2[j * sj] * j2) * ue[j];
+    out[e * Np + i] = acc;
+}
+
 constexpr int kMaxFields = 8;
 struct FieldPtrs {
     const double* v[kMaxFields];

@@ -141,7 +141,7 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_DIV_CASE(DBG) \
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT)
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT, 0)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_DIV_CASE(1); break;
@@ -152,6 +152,22 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
         default: FE_DIV_CASE(0); break;
     }
 #undef FE_DIV_CASE
+    return FE_OK;
+}
+
+template <int NP, int M>
+int launch_divcomp(const double* J, const double* D, const double* u, double* out, int64_t E,
+                   int opT, int jes, hipStream_t s, int64_t* e_done) {
+    using G = fe::DivGeom<NP, M, 1>;
+    const int64_t nTiles = E / G::TEL;
+    *e_done = nTiles * G::TEL;
+    if (nTiles == 0) return FE_OK;
+    static std::once_flag once;
+    static int attr_rc = FE_OK;
+    std::call_once(once, [] { attr_rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
+                       G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT, jes);
     return FE_OK;
 }
 
@@ -243,6 +259,7 @@ int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp
         case FE_FAMILY_DIV: return 2 * 3 * np * np + 2 * 9 * np;
         case FE_FAMILY_GRADDIV: return 2 * (2 * 3 * np * np + 2 * 9 * np);
         case FE_FAMILY_FACEMASS: return (int64_t)b * ((int64_t)nf * Nfp + 2 * np * nf * Nfp);
+        case FE_FAMILY_DIVCOMP: return 3 * np + 2 * 3 * np * np;
         default: return -1;
     }
 }
@@ -326,6 +343,37 @@ int fe_div3d_f64_ex(const double* J, const double* D, const double* u, double* o
     if (e_done < E)
         hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
                            J, D, u, out, E, Np, e_done, opT);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
+                     int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
+    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (op_flags & ~(FE_OP_TRANSPOSED | FE_OP_J_ES))
+        return fail(FE_EINVAL, "div component: bad operator flags %d", op_flags);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "div component: unknown variant %d", variant);
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, jes = (op_flags & FE_OP_J_ES) ? 1 : 0;
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "div component: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
+    int64_t e_done = 0;
+    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+        int rc = FE_OK;
+        switch (Np) {   // wave tile = 16 M elements
+            case 35: rc = launch_divcomp<35, 1>(J, D, u, out, E, opT, jes, s, &e_done); break;
+            case 20: rc = launch_divcomp<20, 2>(J, D, u, out, E, opT, jes, s, &e_done); break;
+            case 10: rc = launch_divcomp<10, 4>(J, D, u, out, E, opT, jes, s, &e_done); break;
+            default: rc = launch_divcomp<4, 6>(J, D, u, out, E, opT, jes, s, &e_done); break;
+        }
+        if (rc != FE_OK) return rc;
+    }
+    if (e_done < E)
+        hipLaunchKernelGGL(fe::divcomp3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
+                           J, D, u, out, E, Np, e_done, opT, jes);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
@@ -472,6 +520,8 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
         case FE_FAMILY_GRADDIV:
             return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
                                     a->variant, stream);
+        case FE_FAMILY_DIVCOMP:
+            return fe_divcomp3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_FACEMASS:
             return fe_facemass_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->nf, a->Nfp, a->b,
                                    a->layout_flags, a->variant, stream);

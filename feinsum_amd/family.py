@@ -13,8 +13,9 @@ Families (SURVEY §8a): grad ``xre,rij,ej->xei``; div ``xre,rij,xej->ei``;
 face-mass ``ef,fij,fej->ei`` with its layout siblings (J as ``fe``, operator as
 ``ifj`` -- ``tuning/impls/ifj_fe_fej_to_ei.py:46-60``), and the transposed-operator
 siblings of all three (``rji``: ``tuning/impls/xre_rji_xej_to_ei_v1.py``; ``fji`` /
-``jfi``: ``tuning/impls/jfi_fe_fej_to_ei.py:46-56``).  Anything else is evaluated by
-the generic einsum kernel.
+``jfi``: ``tuning/impls/jfi_fe_fej_to_ei.py:46-56``); the div component
+``re,rij,ej->ei`` of ``test/test_codegen.py:34-66`` (batched over the three components).
+Anything else is evaluated by the generic einsum kernel.
 """
 
 from __future__ import annotations
@@ -27,9 +28,9 @@ import numpy as np
 
 from feinsum_amd.einsum import BatchedEinsum, SizeParam
 
-FAMILY_GRAD, FAMILY_DIV, FAMILY_GRADDIV, FAMILY_FACEMASS = 1, 2, 3, 4
+FAMILY_GRAD, FAMILY_DIV, FAMILY_GRADDIV, FAMILY_FACEMASS, FAMILY_DIVCOMP = 1, 2, 3, 4, 5
 FM_J_FE, FM_R_IFJ, FM_R_T = 1, 2, 4
-OP_TRANSPOSED = 1
+OP_TRANSPOSED, OP_J_ES = 1, 2
 
 # (family, layout_flags, subscripts, roles of the operands in template order)
 _TEMPLATES = (
@@ -37,6 +38,11 @@ _TEMPLATES = (
     (FAMILY_GRAD, OP_TRANSPOSED, "xre,rji,ej->xei", ("J", "D", "u")),
     (FAMILY_DIV, 0, "xre,rij,xej->ei", ("J", "D", "u")),
     (FAMILY_DIV, OP_TRANSPOSED, "xre,rji,xej->ei", ("J", "D", "u")),     # xre_rji_xej_to_ei_v{0,1}.py
+    # div components: test/test_codegen.py:34-66, re_rij_ej_to_ei.py, re_rji_ej_to_ei_*.py
+    (FAMILY_DIVCOMP, 0, "re,rij,ej->ei", ("J", "D", "u")),
+    (FAMILY_DIVCOMP, OP_TRANSPOSED, "re,rji,ej->ei", ("J", "D", "u")),
+    (FAMILY_DIVCOMP, OP_J_ES, "er,rij,ej->ei", ("J", "D", "u")),        # examples/dg_wave_div.py
+    (FAMILY_DIVCOMP, OP_J_ES | OP_TRANSPOSED, "er,rji,ej->ei", ("J", "D", "u")),
 ) + tuple(
     (FAMILY_FACEMASS, jflag | rflag, f"{jsub},{rsub},fej->ei", ("J", "R", "v"))
     for jflag, jsub in ((0, "ef"), (FM_J_FE, "fe"))
@@ -61,7 +67,8 @@ class KernelPlan:
 
     @property
     def name(self) -> str:
-        return {FAMILY_GRAD: "grad", FAMILY_DIV: "div", FAMILY_FACEMASS: "facemass"}[self.family]
+        return {FAMILY_GRAD: "grad", FAMILY_DIV: "div", FAMILY_FACEMASS: "facemass",
+                FAMILY_DIVCOMP: "divcomp"}[self.family]
 
 
 def _match_template(einsum: BatchedEinsum, subscripts: str) -> Optional[Tuple[Tuple[int, ...], Dict[str, str]]]:
@@ -107,6 +114,10 @@ def match_family(einsum: BatchedEinsum) -> Optional[KernelPlan]:
             continue
         if family in (FAMILY_GRAD, FAMILY_DIV):
             if int(dim("x")) != 3 or int(dim("r")) != 3 or int(dim("i")) != int(dim("j")):
+                continue
+            params = {"Np": int(dim("i"))}
+        elif family == FAMILY_DIVCOMP:
+            if int(dim("r")) != 3 or int(dim("i")) != int(dim("j")):
                 continue
             params = {"Np": int(dim("i"))}
         else:

@@ -44,7 +44,7 @@ from feinsum_amd.contraction_schedule import ContractionSchedule, count_ops
 from feinsum_amd.diagnostics import (HipLibraryError, InvalidParameterError,
                                      NoDevicePeaksInfoError, TransformValidationError)
 from feinsum_amd.einsum import INT_CLASSES, BatchedEinsum, SizeParam
-from feinsum_amd.family import (FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD, KernelPlan,
+from feinsum_amd.family import (FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_FACEMASS, FAMILY_GRAD, KernelPlan,
                                 match_family)
 
 logger = logging.getLogger(__name__)
@@ -222,9 +222,9 @@ class _FamilyLaunch:
         self.E = int(arg_dict[first[role["J"]].name].shape[long_axis])
         self._keep = (arg_dict, outs)
         p = plan.params
-        op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV) else "R"
+        op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP) else "R"
         self.groups = []   # list of ArgPack (one per launch)
-        if plan.family in (FAMILY_GRAD, FAMILY_DIV):
+        if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP):
             for row, out in zip(rows, outs):
                 pack = _hip.ArgPack()
                 pack.J = arg_dict[row[role["J"]].name].data_ptr()
@@ -265,6 +265,9 @@ class _FamilyLaunch:
             elif self.plan.family == FAMILY_DIV:
                 _hip.check(lib.fe_div3d_f64_ex(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
                                                pack.layout_flags, pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_DIVCOMP:
+                _hip.check(lib.fe_divcomp3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
+                                                pack.layout_flags, pack.variant, stream_ptr))
             else:
                 _hip.check(lib.fe_facemass_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                pack.nf, pack.Nfp, pack.b, pack.layout_flags,

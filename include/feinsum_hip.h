@@ -59,6 +59,7 @@ extern "C" {
 #define FE_FAMILY_DIV      2
 #define FE_FAMILY_GRADDIV  3
 #define FE_FAMILY_FACEMASS 4
+#define FE_FAMILY_DIVCOMP  5
 
 /* face-mass operand layouts (bit flags) */
 #define FE_FM_J_EF   0  /* J[E][nf]      (test_loopy_utils.py:41)            */
@@ -102,6 +103,16 @@ int fe_div3d_f64_ex(const double* J, const double* D, const double* u,
                     double* out, int64_t E, int32_t Np, int32_t op_flags,
                     int32_t variant, void* stream);
 
+/* div component:  out[e,i] = sum_{s,j} J[s,e] * D[s,i,j] * u[e,j]
+ * 'se,sij,ej->ei' (test/test_codegen.py:34-66, one row of the batch;
+ * tuning/impls/re_rij_ej_to_ei.py:147-157); op_flags: FE_OP_TRANSPOSED and
+ * FE_OP_J_ES (J stored [E][3]: 'es,sij,ej->ei', examples/dg_wave_div.py:13-22).
+ *   J [3][E]   D [3][Np][Np]   u [E][Np]   out [E][Np]                       */
+#define FE_OP_J_ES 2
+int fe_divcomp3d_f64(const double* J, const double* D, const double* u,
+                     double* out, int64_t E, int32_t Np, int32_t op_flags,
+                     int32_t variant, void* stream);
+
 /* div:   out[e,i] = sum_{x,r,j} J[x,r,e] * D[r,i,j] * u[x,e,j]
  * 'xre,rij,xej->ei' (tuning/impls/xre_rij_xej_to_ei.py:26-60).
  *   J [3][3][E]   D [3][Np][Np]   u [3][E][Np]   out [E][Np]                */
@@ -128,7 +139,8 @@ int fe_facemass_f64(const double* J, const double* R,
 
 /* Algorithmic flops per element for a family (numerator of GFLOP/s; same
  * counter as measure.py:278-331 on the opt_einsum-optimal schedule):
- * grad/div 2*3*Np*Np + 2*9*Np; face-mass b*(nf*Nfp + 2*Np*nf*Nfp). */
+ * grad/div 2*3*Np*Np + 2*9*Np; face-mass b*(nf*Nfp + 2*Np*nf*Nfp);
+ * div component 3*Np + 2*3*Np*Np. */
 int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf,
                              int32_t Nfp, int32_t b);
 

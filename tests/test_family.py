@@ -6,7 +6,7 @@ import random
 import string
 
 import feinsum_amd as f
-from feinsum_amd.family import (FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD, FM_J_FE, FM_R_IFJ, FM_R_T,
+from feinsum_amd.family import (FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_FACEMASS, FAMILY_GRAD, FM_J_FE, FM_R_IFJ, FM_R_T,
                                 OP_TRANSPOSED)
 
 import dg
@@ -28,7 +28,6 @@ def test_basic_matches():
 
 
 def test_non_family():
-    assert f.match_family(dg.batched_div_components()) is None
     A = f.array("A", (10, 4), "float32")
     assert f.match_family(f.einsum("ij,j->i", A, f.array("x", 4, "float32"))) is None
     # right structure, wrong output layout (e and i swapped): memory layout differs
@@ -84,3 +83,15 @@ def test_transposed_operator_siblings():
     assert p.roles == {"J": 1, "R": 0, "v": 2} and p.params == {"Np": 35, "nf": 4, "Nfp": 15}
     p = f.match_family(dg.face_mass_fji())
     assert p.family == FAMILY_FACEMASS and p.layout_flags == FM_R_T
+
+
+def test_div_component_family():
+    # test/test_codegen.py:34-66 'se, sij, ej -> ei' x 3, and the 'es' layout of examples/dg_wave_div.py
+    p = f.match_family(dg.batched_div_components())
+    assert p.family == FAMILY_DIVCOMP and p.layout_flags == 0 and p.params == {"Np": 35}
+    es = f.batched_einsum("es,sij,ej->ei", [[f.array("J" + c, ("E", 3)), f.array("R", (3, 35, 35)),
+                                             f.array("u" + c, ("E", 35))] for c in "xyz"])
+    assert f.match_family(es).layout_flags == 2
+    # 2D (s = 2) is not the 3D kernel
+    e2 = f.einsum("se,sij,ej->ei", f.array("J", (2, "E")), f.array("R", (2, 10, 10)), f.array("u", ("E", 10)))
+    assert f.match_family(e2) is None

@@ -131,6 +131,22 @@ def test_transposed_operators_lower_orders(torch_cuda, Np):
         _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
 
 
+@pytest.mark.parametrize("Np", [4, 10, 20, 35, 56])
+@pytest.mark.parametrize("E", [31, 32, 97, 1003])
+def test_div_components(torch_cuda, Np, E):
+    # 'se,sij,ej->ei' x 3 (test/test_codegen.py:34-66) and its 'es' / transposed-operator layouts
+    import feinsum_amd as f2
+
+    variants = ["auto", "generic"] + (["mfma"] if Np != 56 else [])
+    for subs, jshape in (("se,sij,ej->ei", (3, "E")), ("es,sij,ej->ei", ("E", 3)), ("se,sji,ej->ei", (3, "E"))):
+        expr = f2.batched_einsum(subs, [[f2.array("J" + c, jshape), f2.array("R", (3, Np, Np)),
+                                         f2.array("u" + c, ("E", Np))] for c in "xyz"])
+        host = generate_host_input_arrays(expr, E, np_seed=Np + E)
+        ref = _oracle(expr, host)
+        for v in variants:
+            _assert_close(_run(torch_cuda, expr, host, transform=v), ref)
+
+
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
 def test_face_mass_field_counts(torch_cuda, b):
     # b = 1 (generic only), odd counts, > 8 fields (several launches), 19 as in the archive
