@@ -66,8 +66,22 @@ def _device_inputs(expr, E, device, seed):
     return dev
 
 
+def _cpu_share() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup quota).  Oversubscribing a
+    quota-limited box is several times slower (MI355X box: quota 16 CPUs, 256 visible)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_baseline(workload: str, budget_s: float = 12.0):
     """The oracle's C loop nest (optimal 2-step schedule, OpenMP) timed on the host cores."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_share()))   # before the OpenMP runtime starts
     import numpy as np
 
     from oracle import c_oracle, np_oracle
@@ -109,7 +123,8 @@ def _cpu_baseline(workload: str, budget_s: float = 12.0):
         "value": round(flops * reps / t_total * 1e-9, 2), "unit": "GFLOP/s", "cores": threads,
         "kind": "port",
         "sample": (f"oracle/loopnest.c {what} p=4 optimal 2-step schedule, gcc -O3 -march=native -fopenmp, "
-                   f"{reps} x E={E} elements ({t_total:.1f} s) on {threads} threads of {os.cpu_count()} host CPUs"),
+                   f"{reps} x E={E} elements ({t_total:.1f} s) on {threads} threads "
+                   f"(CPU share of this box; {os.cpu_count()} host CPUs visible)"),
     }
 
 
