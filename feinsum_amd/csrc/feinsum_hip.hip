@@ -59,11 +59,28 @@ int set_max_lds(K kernel, int bytes) {
     return FE_OK;
 }
 
+// Kernel attributes are per device: a `static std::once_flag` per kernel would configure only
+// the first device a process uses.  One flag per (call site, device).
+struct PerDeviceOnce {
+    std::once_flag flags[64];
+    int rc[64] = {};
+    template <typename F>
+    int run(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::call_once(flags[dev], [&] { rc[dev] = f(); });
+        return rc[dev];
+    }
+};
+
 int check_common(const void* J, const void* D, const void* u, const void* out, int64_t E,
                  int32_t Np) {
     if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
     if (Np <= 0) return fail(FE_EINVAL, "Np must be positive (got %d)", Np);
     if (E > 0 && (!J || !D || !u || !out)) return fail(FE_EINVAL, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(J) | reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(u) |
+         reinterpret_cast<uintptr_t>(out)) & 7u)
+        return fail(FE_EINVAL, "device pointers must be 8-byte aligned (float64 arrays)");
     if (E * (int64_t)Np >= (int64_t)1 << 39)
         return fail(FE_EINVAL, "E*Np too large (%lld)", (long long)(E * Np));
     return FE_OK;
@@ -86,10 +103,9 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles * G::TEL;
     if (nTiles == 0) return FE_OK;
-    static std::once_flag once;
-    static int attr_rc = FE_OK;
-    std::call_once(once, [] {
-        attr_rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] {
+        int rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
             set_max_lds(fe::grad3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
@@ -99,6 +115,7 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
             set_max_lds(fe::grad3d_mfma_kernel<NP, M, 96>, G::LDS_BYTES);
         }
 #endif
+        return rc;
     });
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
@@ -125,10 +142,9 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles * G::TEL;
     if (nTiles == 0) return FE_OK;
-    static std::once_flag once;
-    static int attr_rc = FE_OK;
-    std::call_once(once, [] {
-        attr_rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] {
+        int rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
             set_max_lds(fe::div3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
@@ -137,6 +153,7 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
             set_max_lds(fe::div3d_mfma_kernel<NP, M, 8>, G::LDS_BYTES);
         }
 #endif
+        return rc;
     });
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
@@ -162,9 +179,8 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles * G::TEL;
     if (nTiles == 0) return FE_OK;
-    static std::once_flag once;
-    static int attr_rc = FE_OK;
-    std::call_once(once, [] { attr_rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
                        G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT, jes);
@@ -175,9 +191,8 @@ template <int NP, int NFP, int M, int NB>
 int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
     using G = fe::FmGeom<NP, NFP, M>;
-    static std::once_flag once;
-    static int attr_rc = FE_OK;
-    std::call_once(once, [] { attr_rc = set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB>, G::LDS_BYTES); });
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB>), dim3(persistent_grid(nTiles, G::WAVES)),
                        dim3(256), G::LDS_BYTES, s, J, R, P, E, nTiles, jfe, rifj);
@@ -400,8 +415,13 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
     if (!v || !out) return fail(FE_EINVAL, "face-mass: null pointer table");
     if (E == 0) return FE_OK;
     if (!J || !R) return fail(FE_EINVAL, "face-mass: null device pointer");
-    for (int k = 0; k < b; ++k)
+    for (int k = 0; k < b; ++k) {
         if (!v[k] || !out[k]) return fail(FE_EINVAL, "face-mass: null field pointer %d", k);
+        if ((reinterpret_cast<uintptr_t>(v[k]) | reinterpret_cast<uintptr_t>(out[k])) & 7u)
+            return fail(FE_EINVAL, "face-mass: field pointers must be 8-byte aligned");
+    }
+    if ((reinterpret_cast<uintptr_t>(J) | reinterpret_cast<uintptr_t>(R)) & 7u)
+        return fail(FE_EINVAL, "face-mass: device pointers must be 8-byte aligned");
     if (E * (int64_t)Np >= (int64_t)1 << 39) return fail(FE_EINVAL, "E*Np too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
 

@@ -22,7 +22,7 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     lib = _hip.load_library()
     declared = _declared_symbols()
-    assert len(declared) >= 11
+    assert len(declared) >= 14
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/feinsum_hip.h but not exported"
     assert set(declared) == set(_hip.EXPORTED_SYMBOLS)
@@ -35,6 +35,7 @@ def test_version_and_flop_counters():
     assert _hip.flops_per_element(2, 35) == 7980            # div
     assert _hip.flops_per_element(3, 35) == 15960           # fused grad + div
     assert _hip.flops_per_element(4, 35, 4, 15, 4) == 17040  # face-mass x4
+    assert _hip.flops_per_element(5, 35) == 7455             # div component (x3 = 22365)
     assert _hip.flops_per_element(99, 35) == -1
 
 
@@ -49,6 +50,12 @@ def test_argument_validation_without_gpu():
         _hip.grad3d(0, 0, 0, 0, 10, 35)
     with pytest.raises(NotImplementedError, match="unknown variant"):
         _hip.grad3d(8, 8, 8, 8, 10, 35, variant=7)
+    with pytest.raises(InvalidParameterError, match="8-byte aligned"):
+        _hip.div3d(8, 8, 12, 8, 10, 35)
+    with pytest.raises(InvalidParameterError, match="operator flags"):
+        _hip.grad3d(8, 8, 8, 8, 10, 35, op_flags=4)
+    with pytest.raises(InvalidParameterError, match="operator flags"):
+        _hip.divcomp3d(8, 8, 8, 8, 10, 35, op_flags=8)
     with pytest.raises(InvalidParameterError, match="unknown kernel variant"):
         _hip.grad3d(8, 8, 8, 8, 10, 35, variant="fastest")
     with pytest.raises(InvalidParameterError, match="layout"):
