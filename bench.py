@@ -81,12 +81,12 @@ def _cpu_share() -> int:
 
 def _cpu_baseline(workload: str, budget_s: float = 12.0):
     """The oracle's C loop nest (optimal 2-step schedule, OpenMP) timed on the host cores."""
-    os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_share()))   # before the OpenMP runtime starts
     import numpy as np
 
     from oracle import c_oracle, np_oracle
 
     lib_native = c_oracle.load(native=True)
+    lib_native.oracle_set_num_threads(_cpu_share())   # (the OpenMP runtime is already up: torch)
     threads = int(lib_native.oracle_num_threads())
     E = 200_000
     rng = np.random.default_rng(0)

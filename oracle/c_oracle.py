@@ -51,6 +51,8 @@ def _typed(lib):
         fn.restype = None
         fn.argtypes = [dp, dp, dp, dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_set_num_threads.restype = None
+    lib.oracle_set_num_threads.argtypes = [C.c_int]
     return lib
 
 

@@ -127,6 +127,15 @@ void oracle_facemass_hoisted(const double* J, const double* R, const double* v, 
     }
 }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);
