@@ -25,6 +25,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MF
 EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
     "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
+    "fe_grad3d_batched_f64", "fe_div3d_batched_f64",
     "fe_graddiv3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
@@ -105,6 +106,11 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    for name in ("fe_grad3d_batched_f64", "fe_div3d_batched_f64"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                       C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_graddiv3d_f64.restype = C.c_int
     lib.fe_graddiv3d_f64.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_facemass_f64.restype = C.c_int
@@ -177,6 +183,24 @@ def div3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, strea
 def divcomp3d(J: int, D: int, u: int, out: int, E: int, Np: int, variant=None, stream: int = 0,
               op_flags: int = 0) -> None:
     check(load_library().fe_divcomp3d_f64(J, D, u, out, E, Np, op_flags, variant_code(variant), stream))
+
+
+def grad3d_batched(J: int, D: int, u: Sequence[int], out: Sequence[int], E: int, Np: int,
+                   variant=None, stream: int = 0, op_flags: int = 0) -> None:
+    """``len(u)`` fields through one grad launch, sharing J and D."""
+    if len(u) != len(out):
+        raise InvalidParameterError("grad: need as many outputs as fields")
+    check(load_library().fe_grad3d_batched_f64(J, D, _ptr_array(u), _ptr_array(out), E, Np, len(u),
+                                               op_flags, variant_code(variant), stream))
+
+
+def div3d_batched(J: int, D: int, u: Sequence[int], out: Sequence[int], E: int, Np: int,
+                  variant=None, stream: int = 0, op_flags: int = 0) -> None:
+    """``len(u)`` fields through one div launch, sharing J and D."""
+    if len(u) != len(out):
+        raise InvalidParameterError("div: need as many outputs as fields")
+    check(load_library().fe_div3d_batched_f64(J, D, _ptr_array(u), _ptr_array(out), E, Np, len(u),
+                                              op_flags, variant_code(variant), stream))
 
 
 def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: int, E: int,

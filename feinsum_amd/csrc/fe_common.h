@@ -11,6 +11,28 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define FE_AS1 __attribute__((address_space(1)))
 #define FE_AS3 __attribute__((address_space(3)))
 
+// Per-field device pointers of a batched launch (by value in the kernel arguments).
+constexpr int kMaxFields = 8;
+struct FieldPtrs {
+    const double* v[kMaxFields];
+    double* out[kMaxFields];
+};
+
+// Field k of a batched launch, k wave-uniform and only known at run time: a select chain over
+// the kernel arguments (scalar ALU) instead of an indexed copy of the struct in scratch.
+__device__ __forceinline__ const double* field_in(const FieldPtrs& P, int k) {
+    const double* p = P.v[0];
+#pragma unroll
+    for (int q = 1; q < kMaxFields; ++q) p = (k == q) ? P.v[q] : p;
+    return p;
+}
+__device__ __forceinline__ double* field_out(const FieldPtrs& P, int k) {
+    double* p = P.out[0];
+#pragma unroll
+    for (int q = 1; q < kMaxFields; ++q) p = (k == q) ? P.out[q] : p;
+    return p;
+}
+
 // 32-bit LDS byte address of a generic pointer into __shared__ memory, made
 // provably wave-uniform (it is moved into M0 by the LDS-DMA helpers).
 __device__ __forceinline__ unsigned lds_addr_uniform(const void* p) {

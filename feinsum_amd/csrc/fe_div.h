@@ -65,8 +65,8 @@ struct DivGeom {
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
 template <int NP, int M, int kDbg = 0, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int64_t nTiles, int opT, int jes) {
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
+    int64_t nTiles, int opT, int jes) {
     using G = DivGeom<NP, M, MODE>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,9 +106,12 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)gridDim.x * G::WAVES;
-    auto issue_loads = [&](int64_t tile) {
+    // nb fields share J and D ('xre,rij,xej->ei' x nb: tuning/impls/batched_xre_rij_xej_to_ei.py):
+    // the wave walks (tile, field) units, field fastest; J is loaded with the first field of a
+    // tile and stays in LDS until the last field's B fragments are built.
+    auto issue_loads = [&](int64_t tile, int fk, bool with_j) {
         const int64_t e0 = tile * G::TEL;
-        const char* ub = reinterpret_cast<const char*>(u) + e0 * (NP * 8) + lane * 16;
+        const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8) + lane * 16;
 #pragma unroll
         for (int x = 0; x < G::NPLANES; ++x) {
             const char* up = ub + (int64_t)x * E * (NP * 8);
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
                 if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
                     glds16_nt(up + c * 1024, lds_u + x * (G::PLANE_D * 8) + c * 1024);
         }
+        if (!with_j) return;
         const char* jb = reinterpret_cast<const char*>(J) + e0 * 8;
 #pragma unroll
         for (int c = 0; c < G::J_INSTR; ++c) {
@@ -129,13 +133,17 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     };
     int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
     bool first = true;
-    if (tile < nTiles && !(kDbg & 8)) issue_loads(tile);
+    if (tile < nTiles && !(kDbg & 8)) issue_loads(tile, 0, true);
     const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
-    int iteration = 0;
-    for (; tile < nTiles; tile += stride) {
+    int iteration = 0, fk = 0;
+    while (tile < nTiles) {
         balance_priority(younger_half, iteration++);
         const int64_t e0 = tile * G::TEL;
-        // issue order: ... L(t) [MFMAs(t-1)] S(t-1) | wait L(t): the previous tile's stores are younger
+        double* const out = field_out(P, fk);
+        const bool next_new_tile = (fk + 1 == nb);
+        const int64_t nt = next_new_tile ? tile + stride : tile;
+        const int nk = next_new_tile ? 0 : fk + 1;
+        // issue order: ... L(unit) [MFMAs(unit-1)] S(unit-1) | wait L(unit): the previous unit's stores are younger
         if (first || (kDbg & 10)) wait_vmcnt<0>();
         else wait_vmcnt<G::STORES>();
         first = false;
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
             for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
-        if (tile + stride < nTiles && !(kDbg & 8)) issue_loads(tile + stride);
+        if (nt < nTiles && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
 
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -231,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
             }
             wave_lds_fence();
         }
+        fk = nk;
+        tile = nt;
     }
 }
 

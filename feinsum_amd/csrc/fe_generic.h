@@ -59,12 +59,6 @@ __global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
     out[e * Np + i] = acc;
 }
 
-constexpr int kMaxFields = 8;
-struct FieldPtrs {
-    const double* v[kMaxFields];
-    double* out[kMaxFields];
-};
-
 // face-mass: out_k[e,i] = sum_{f,j} J[e,f] R[f,i,j] v_k[f,e,j]
 //   jEs / jFs : strides of J along e and f;  rF / rI / rJ : strides of R along f, i and j
 template <int NB>

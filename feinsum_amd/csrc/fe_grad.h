@@ -57,12 +57,13 @@ struct GradGeom {
     static constexpr int J_INSTR = (J_CHUNKS + 63) / 64;
     static constexpr int SUB_CHUNKS = SUB_D / 2;
     static constexpr int SUB_INSTR = (SUB_CHUNKS + 63) / 64;
-    static constexpr int LOADS = U_INSTR + J_INSTR;    // vector-memory ops per tile: loads ...
+    static constexpr int LOADS = U_INSTR + J_INSTR;    // vector-memory ops per (tile, field) unit: loads
+                                                       // (J only with the first field of a tile) ...
     static constexpr int STORES = 3 * M * SUB_INSTR;   // ... and stores
     struct WaveLds {
         double u[2][TILE_D];     // prefetch double buffer
         double o[2][SUB_D];      // output transposition buffers, alternating
-        double j[2][9 * TEL];    // J[x*3+r][e0 + 0..TEL-1], double buffered
+        double j[2][9 * TEL];    // J[x*3+r][e0 + 0..TEL-1], double buffered (by tile)
     };
     static constexpr int WAVES = 4;
     static constexpr int OP_D = 3 * NP * NP;           // operator doubles (staged once per block)
@@ -74,21 +75,23 @@ struct GradGeom {
 };
 
 template <int NP, int M, bool kNT = true>
-__device__ __forceinline__ void grad_issue_loads(const double* __restrict__ J,
-                                                    const double* __restrict__ u, int64_t E,
-                                                    int64_t tile, int lane, unsigned lds_u,
-                                                    unsigned lds_j) {
+__device__ __forceinline__ void grad_issue_u(const double* __restrict__ u, int64_t tile, int lane,
+                                             unsigned lds_u) {
     using G = GradGeom<NP, M>;
-    const int64_t e0 = tile * G::TEL;
-    const char* ub = reinterpret_cast<const char*>(u) + e0 * (NP * 8) + lane * 16;
+    const char* ub = reinterpret_cast<const char*>(u) + tile * (G::TEL * NP * 8) + lane * 16;
 #pragma unroll
     for (int c = 0; c < G::U_INSTR; ++c)
-        if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS)
-        {
+        if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) {
             if (kNT) glds16_nt(ub + c * 1024, lds_u + c * 1024);
             else glds16(ub + c * 1024, lds_u + c * 1024);
         }
-    const char* jb = reinterpret_cast<const char*>(J) + e0 * 8;
+}
+
+template <int NP, int M>
+__device__ __forceinline__ void grad_issue_j(const double* __restrict__ J, int64_t E, int64_t tile,
+                                             int lane, unsigned lds_j) {
+    using G = GradGeom<NP, M>;
+    const char* jb = reinterpret_cast<const char*>(J) + tile * (G::TEL * 8);
 #pragma unroll
     for (int c = 0; c < G::J_INSTR; ++c) {
         const int q = c * 64 + lane;                      // chunk -> (row, column chunk)
@@ -111,10 +114,13 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 // 8 skip loads, 16 plain (temporal) loads, 32 per-wave timestamps, 64 no priority balancing.
 // Product: non-temporal on both sides -- every byte is touched once (A/B on MI355X: -2.5 %
 // kernel time, -7 % for the data-movement skeleton).
+// nb: fields per launch ('xre,rij,ej->xei' x NB sharing J and D: tuning/impls/
+// batched_xre_rij_ej_to_xei.py): J is loaded once per tile and serves all nb fields;
+// the wave walks (tile, field) units, field fastest.
 template <int NP, int M, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int64_t nTiles, int opT) {
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
+    int64_t nTiles, int opT) {
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,38 +156,48 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
 
     const int64_t stride = (int64_t)gridDim.x * G::WAVES;
     int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
-    int buf = 0;
+    int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
     constexpr bool kNT = (kDbg & 16) == 0;
-    if (tile < nTiles && !(kDbg & 8))
-        grad_issue_loads<NP, M, kNT>(J, u, E, tile, lane, lds_addr_uniform(L->u[0]), lds_addr_uniform(L->j[0]));
+    if (tile < nTiles && !(kDbg & 8)) {
+        grad_issue_u<NP, M, kNT>(P.v[0], tile, lane, lds_addr_uniform(L->u[0]));
+        grad_issue_j<NP, M>(J, E, tile, lane, lds_addr_uniform(L->j[0]));
+    }
 #ifdef FE_EXPERIMENTS
     unsigned long long c0 = 0, r0 = 0;
     if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
     const bool younger_half = !(kDbg & 64) && blockIdx.x >= (gridDim.x + 1) / 2;
-    int iteration = 0;
-    for (; tile < nTiles; tile += stride, buf ^= 1) {
+    int iteration = 0, fk = 0;
+    while (tile < nTiles) {
         balance_priority(younger_half, iteration++);
-        // Vector-memory ops in issue order: L(t) S(t-1) L(t+1) | wait L(t).  The stores of the
-        // previous tile and the loads of the next one are younger than this tile's loads and
-        // stay in flight.
-        const int64_t nxt = tile + stride;
+        // Vector-memory ops in issue order: L(unit) S(previous unit) L(next unit) | wait L(unit).
+        // The stores of the previous unit and the loads of the next one are younger than this
+        // unit's loads and stay in flight.
+        const bool next_new_tile = (fk + 1 == nb);
+        const int64_t nt = next_new_tile ? tile + stride : tile;
+        const int nk = next_new_tile ? 0 : fk + 1;
         if (kDbg & 8) {
             wait_vmcnt<0>();
-        } else if (nxt < nTiles) {
-            grad_issue_loads<NP, M, kNT>(J, u, E, nxt, lane, lds_addr_uniform(L->u[buf ^ 1]),
-                                         lds_addr_uniform(L->j[buf ^ 1]));
-            if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
-            else wait_vmcnt<G::LOADS + G::STORES>();
+        } else if (nt < nTiles) {
+            grad_issue_u<NP, M, kNT>(field_in(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
+            if (next_new_tile) {
+                grad_issue_j<NP, M>(J, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
+                if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
+                else wait_vmcnt<G::LOADS + G::STORES>();
+            } else {
+                if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
+                else wait_vmcnt<G::U_INSTR + G::STORES>();
+            }
         } else {
             if (first || (kDbg & 2)) wait_vmcnt<0>();
             else wait_vmcnt<G::STORES>();
         }
         first = false;
 
-        const double* ut = L->u[buf];
-        const double* jt = L->j[buf];
+        const double* ut = L->u[ub];
+        const double* jt = L->j[jbuf];
+        double* const out = field_out(P, fk);
         const int64_t e0 = tile * G::TEL;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -240,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
                 wave_lds_fence();
             }
         }
+        fk = nk;
+        tile = nt;
+        ub ^= 1;
+        if (next_new_tile) jbuf ^= 1;
     }
 #ifdef FE_EXPERIMENTS
     if ((kDbg & 32) && lane == 0) {

@@ -97,7 +97,7 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
 }
 
 template <int NP, int M>
-int launch_grad(const double* J, const double* D, const double* u, double* out, int64_t E,
+int launch_grad(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E,
                 int dbg, int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::GradGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
@@ -120,7 +120,7 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT)
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
@@ -136,7 +136,7 @@ int launch_grad(const double* J, const double* D, const double* u, double* out, 
 }
 
 template <int NP, int M>
-int launch_div(const double* J, const double* D, const double* u, double* out, int64_t E, int dbg,
+int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int dbg,
                int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;
@@ -158,7 +158,7 @@ int launch_div(const double* J, const double* D, const double* u, double* out, i
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_DIV_CASE(DBG) \
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT, 0)
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_DIV_CASE(1); break;
@@ -182,8 +182,11 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     static PerDeviceOnce once;
     const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
+    fe::FieldPtrs P = {};
+    P.v[0] = u;
+    P.out[0] = out;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
-                       G::LDS_BYTES, s, J, D, u, out, E, nTiles, opT, jes);
+                       G::LDS_BYTES, s, J, D, P, 1, E, nTiles, opT, jes);
     return FE_OK;
 }
 
@@ -286,7 +289,25 @@ int fe_grad3d_f64(const double* J, const double* D, const double* u, double* out
 
 int fe_grad3d_f64_ex(const double* J, const double* D, const double* u, double* out, int64_t E,
                      int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
-    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    return fe_grad3d_batched_f64(J, D, &u, &out, E, Np, 1, op_flags, variant, stream);
+}
+
+int fe_grad3d_batched_f64(const double* J, const double* D, const double* const* u,
+                          double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                          int32_t variant, void* stream) {
+    if (!u || !out) return fail(FE_EINVAL, "grad: null pointer table");
+    if (b < 1) return fail(FE_EINVAL, "grad: b=%d, need at least one field", b);
+    if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
+        if (int rc = fe_grad3d_batched_f64(J, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
+        return fe_grad3d_batched_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
+                    variant, stream);
+    }
+    fe::FieldPtrs P = {};
+    for (int k = 0; k < b; ++k) {
+        if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
+        P.v[k] = u[k];
+        P.out[k] = out[k];
+    }
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
@@ -308,16 +329,17 @@ int fe_grad3d_f64_ex(const double* J, const double* D, const double* u, double* 
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_grad<35, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_grad<20, 2>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_grad<10, 3>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_grad<4, 5>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_grad<35, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_grad<20, 2>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_grad<10, 3>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_grad<4, 5>(J, D, P, b, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
     if (e_done < E)
-        hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
-                           J, D, u, out, E, Np, e_done, opT);
+        for (int k = 0; k < b; ++k)
+            hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256),
+                               0, s, J, D, P.v[k], P.out[k], E, Np, e_done, opT);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
@@ -329,7 +351,25 @@ int fe_div3d_f64(const double* J, const double* D, const double* u, double* out,
 
 int fe_div3d_f64_ex(const double* J, const double* D, const double* u, double* out, int64_t E,
                     int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
-    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    return fe_div3d_batched_f64(J, D, &u, &out, E, Np, 1, op_flags, variant, stream);
+}
+
+int fe_div3d_batched_f64(const double* J, const double* D, const double* const* u,
+                         double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                         int32_t variant, void* stream) {
+    if (!u || !out) return fail(FE_EINVAL, "div: null pointer table");
+    if (b < 1) return fail(FE_EINVAL, "div: b=%d, need at least one field", b);
+    if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
+        if (int rc = fe_div3d_batched_f64(J, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
+        return fe_div3d_batched_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
+                    variant, stream);
+    }
+    fe::FieldPtrs P = {};
+    for (int k = 0; k < b; ++k) {
+        if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
+        P.v[k] = u[k];
+        P.out[k] = out[k];
+    }
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "div: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
@@ -348,16 +388,17 @@ int fe_div3d_f64_ex(const double* J, const double* D, const double* u, double* o
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_div<35, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_div<20, 1>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_div<10, 3>(J, D, u, out, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_div<4, 5>(J, D, u, out, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_div<35, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_div<20, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_div<10, 3>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_div<4, 5>(J, D, P, b, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
     if (e_done < E)
-        hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
-                           J, D, u, out, E, Np, e_done, opT);
+        for (int k = 0; k < b; ++k)
+            hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256),
+                               0, s, J, D, P.v[k], P.out[k], E, Np, e_done, opT);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
@@ -534,8 +575,14 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
 static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
     switch (family) {
         case FE_FAMILY_GRAD:
+            if (a->b > 1)
+                return fe_grad3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
+                                             a->variant, stream);
             return fe_grad3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_DIV:
+            if (a->b > 1)
+                return fe_div3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
+                                            a->variant, stream);
             return fe_div3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_GRADDIV:
             return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,

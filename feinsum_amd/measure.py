@@ -224,47 +224,39 @@ class _FamilyLaunch:
         p = plan.params
         op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP) else "R"
         self.groups = []   # list of ArgPack (one per launch)
-        if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP):
-            for row, out in zip(rows, outs):
-                pack = _hip.ArgPack()
-                pack.J = arg_dict[row[role["J"]].name].data_ptr()
-                pack.D = arg_dict[row[role[op_role]].name].data_ptr()
-                pack.u = arg_dict[row[role["u"]].name].data_ptr()
-                pack.out = out.data_ptr()
-                pack.E, pack.Np, pack.variant = self.E, p["Np"], self.variant
-                pack.layout_flags = plan.layout_flags      # FE_OP_* for grad / div
-                self.groups.append(pack)
-        else:
-            # consecutive rows sharing J and R become one multi-field launch
-            k = 0
-            while k < len(rows):
-                jn, rn = rows[k][role["J"]].name, rows[k][role[op_role]].name
-                k2 = k
-                while (k2 < len(rows) and rows[k2][role["J"]].name == jn
-                       and rows[k2][role[op_role]].name == rn):
-                    k2 += 1
-                vptrs = [arg_dict[rows[m][role["v"]].name].data_ptr() for m in range(k, k2)]
-                optrs = [outs[m].data_ptr() for m in range(k, k2)]
-                pack = _hip.ArgPack()
-                pack.J = arg_dict[jn].data_ptr()
-                pack.D = arg_dict[rn].data_ptr()
-                va, oa = _hip._ptr_array(vptrs), _hip._ptr_array(optrs)
-                self._keep += (va, oa)
-                pack.v, pack.outs = va, oa
-                pack.E, pack.Np, pack.nf, pack.Nfp = self.E, p["Np"], p["nf"], p["Nfp"]
-                pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
-                self.groups.append(pack)
-                k = k2
+        in_role = "u" if op_role == "D" else "v"
+        # consecutive rows sharing J and the operator become one multi-field launch
+        k = 0
+        while k < len(rows):
+            jn, rn = rows[k][role["J"]].name, rows[k][role[op_role]].name
+            k2 = k + 1
+            while (plan.family != FAMILY_DIVCOMP and k2 < len(rows)
+                   and rows[k2][role["J"]].name == jn and rows[k2][role[op_role]].name == rn):
+                k2 += 1
+            vptrs = [arg_dict[rows[m][role[in_role]].name].data_ptr() for m in range(k, k2)]
+            optrs = [outs[m].data_ptr() for m in range(k, k2)]
+            pack = _hip.ArgPack()
+            pack.J = arg_dict[jn].data_ptr()
+            pack.D = arg_dict[rn].data_ptr()
+            pack.u, pack.out = vptrs[0], optrs[0]
+            va, oa = _hip._ptr_array(vptrs), _hip._ptr_array(optrs)
+            self._keep += (va, oa)
+            pack.v, pack.outs = va, oa
+            pack.E, pack.Np = self.E, p["Np"]
+            pack.nf, pack.Nfp = p.get("nf", 0), p.get("Nfp", 0)
+            pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
+            self.groups.append(pack)
+            k = k2
 
     def launch(self, stream_ptr: int) -> None:
         lib = _hip.load_library()
         for pack in self.groups:
             if self.plan.family == FAMILY_GRAD:
-                _hip.check(lib.fe_grad3d_f64_ex(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
-                                                pack.layout_flags, pack.variant, stream_ptr))
+                _hip.check(lib.fe_grad3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
+                                                     pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIV:
-                _hip.check(lib.fe_div3d_f64_ex(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
-                                               pack.layout_flags, pack.variant, stream_ptr))
+                _hip.check(lib.fe_div3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
+                                                    pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIVCOMP:
                 _hip.check(lib.fe_divcomp3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
                                                 pack.layout_flags, pack.variant, stream_ptr))

@@ -70,6 +70,8 @@ extern "C" {
                            with FE_FM_R_IFJ  L[Nfp][nf][Np]  ('jfi',
                            tuning/impls/jfi_fe_fej_to_ei.py:46-56)           */
 
+#define FE_MAX_FIELDS 8  /* fields per batched grad / div launch (more are split) */
+
 /* operator flags for the _ex entry points of grad / div */
 #define FE_OP_TRANSPOSED 1 /* D stored [3][Np(j)][Np(i)]: 'xre,rji,ej->xei',
                               'xre,rji,xej->ei' (tuning/impls/xre_rji_xej_to_ei_v1.py) */
@@ -120,6 +122,22 @@ int fe_div3d_f64(const double* J, const double* D, const double* u,
                  double* out, int64_t E, int32_t Np, int32_t variant,
                  void* stream);
 
+/* b fields through one grad / div launch, sharing J and D (the geometry factors are read once
+ * per element instead of b times):
+ *   'xre,rij,ej->xei' x b   (tuning/impls/batched_xre_rij_ej_to_xei.py)
+ *   'xre,rij,xej->ei' x b   (tuning/impls/batched_xre_rij_xej_to_ei.py, _v2, _v3)
+ *   u, out: HOST arrays of b >= 1 device pointers; shapes per field as in fe_grad3d_f64 /
+ *   fe_div3d_f64.  b == 1 is fe_grad3d_f64_ex / fe_div3d_f64_ex; more than FE_MAX_FIELDS
+ *   fields are split over several launches. */
+int fe_grad3d_batched_f64(const double* J, const double* D,
+                          const double* const* u, double* const* out,
+                          int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                          int32_t variant, void* stream);
+int fe_div3d_batched_f64(const double* J, const double* D,
+                         const double* const* u, double* const* out,
+                         int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                         int32_t variant, void* stream);
+
 /* fused grad + div sharing J and D (BASELINE config 3):
  *   grad_out[3][E][Np] from u_grad[E][Np];  div_out[E][Np] from v_div[3][E][Np] */
 int fe_graddiv3d_f64(const double* J, const double* D,
@@ -153,8 +171,8 @@ typedef struct fe_argpack {
     const double* v_div;      /* graddiv only                                 */
     double* out;              /* grad / div output; graddiv: grad_out         */
     double* out2;             /* graddiv: div_out                             */
-    const double* const* v;   /* face-mass inputs  (host array of b ptrs)     */
-    double* const* outs;      /* face-mass outputs (host array of b ptrs)     */
+    const double* const* v;   /* face-mass, batched grad / div (b > 1): inputs  */
+    double* const* outs;      /* ... and outputs (host arrays of b ptrs)        */
     int64_t E;
     int32_t Np, nf, Nfp, b, layout_flags, variant;   /* layout_flags: FE_FM_* or FE_OP_* by family */
 } fe_argpack;

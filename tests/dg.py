@@ -74,3 +74,19 @@ def face_mass_fji(b=4, Np=NP, nf=NF, Nfp=NFP):
         "ef,fji,fej->ei",
         [[f.array("J", ("E", nf)), f.array("R", (nf, Nfp, Np)), f.array(f"v{i}", (nf, "E", Nfp))]
          for i in range(b)])
+
+
+def batched_grad(b=3, Np=NP, op="rij"):
+    # b fields sharing J and the operator: tuning/impls/batched_xre_rij_ej_to_xei.py
+    return f.batched_einsum(
+        f"xre,{op},ej->xei",
+        [[f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)), f.array(f"u{i}", ("E", Np))]
+         for i in range(b)])
+
+
+def batched_div(b=3, Np=NP, op="rij"):
+    # tuning/impls/batched_xre_rij_xej_to_ei.py (_v2, _v3)
+    return f.batched_einsum(
+        f"xre,{op},xej->ei",
+        [[f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)), f.array(f"u{i}", (3, "E", Np))]
+         for i in range(b)])

@@ -147,6 +147,47 @@ def test_div_components(torch_cuda, Np, E):
             _assert_close(_run(torch_cuda, expr, host, transform=v), ref)
 
 
+@pytest.mark.parametrize("Np", [4, 10, 20, 35])
+@pytest.mark.parametrize("b", [2, 3, 5, 6, 8, 11])
+@pytest.mark.parametrize("E", [15, 16, 97, 1003])
+def test_batched_grad_div_share_geometry_factors(torch_cuda, Np, b, E):
+    # 'xre,rij,ej->xei' x b and 'xre,rij,xej->ei' x b with one J and one operator
+    # (tuning/impls/batched_xre_rij_ej_to_xei.py, batched_xre_rij_xej_to_ei.py; b = 3, 5, 6 are the
+    # archive's cases): all fields go through one launch, more than 8 through two
+    for expr in (dg.batched_grad(b, Np), dg.batched_div(b, Np)):
+        host = generate_host_input_arrays(expr, E, np_seed=Np + b + E)
+        ref = _oracle(expr, host)
+        _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
+        _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
+
+
+def test_batched_grad_div_row_grouping(torch_cuda):
+    # rows that do not share J (or the operator) are separate launches; transposed operator
+    import feinsum_amd as f2
+
+    E, Np = 1003, 35
+    rows = [[f2.array("Ja" if i < 2 else "Jb", (3, 3, "E")), f2.array("R" if i != 3 else "R2", (3, Np, Np)),
+             f2.array(f"u{i}", ("E", Np))] for i in range(5)]
+    for expr in (f2.batched_einsum("xre,rij,ej->xei", rows), dg.batched_grad(4, Np, "rji"),
+                 dg.batched_div(4, Np, "rji")):
+        host = generate_host_input_arrays(expr, E, np_seed=5)
+        ref = _oracle(expr, host)
+        _assert_close(_run(torch_cuda, expr, host), ref)
+        _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
+
+
+def test_batched_grad_matches_single_field_launches_bitwise(torch_cuda):
+    # the multi-field walk only changes the order of tiles, never the arithmetic of a tile
+    E, Np, b = 16 * 700 + 5, 35, 3
+    expr = dg.batched_grad(b, Np)
+    host = generate_host_input_arrays(expr, E, np_seed=1)
+    got = _run(torch_cuda, expr, host)
+    single = dg.grad(Np)
+    for k, name in enumerate(expr.output_names):
+        one = _run(torch_cuda, single, {"J": host["J"], "R": host["R"], "u": host[f"u{k}"]})
+        assert np.array_equal(got[name], next(iter(one.values())))
+
+
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
 def test_face_mass_field_counts(torch_cuda, b):
     # b = 1 (generic only), odd counts, > 8 fields (several launches), 19 as in the archive
