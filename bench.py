@@ -50,7 +50,8 @@ def _einsums():
         "ef,fij,fej->ei",
         [[f.array("Jf", ("E", NF)), f.array("L", (NF, NP, NFP)), f.array(f"w{k}", (NF, "E", NFP))]
          for k in range(NFIELDS)])
-    return {"grad": [grad], "div": [div], "facemass": [fm], "pipeline": [div, grad, fm]}
+    return {"grad": [grad], "div": [div], "facemass": [fm], "graddiv": [div, grad],
+            "pipeline": [div, grad, fm]}
 
 
 def _device_inputs(expr, E, device, seed):
@@ -90,7 +91,7 @@ def _cpu_baseline(workload: str, budget_s: float = 12.0):
     threads = int(lib_native.oracle_num_threads())
     E = 200_000
     rng = np.random.default_rng(0)
-    if workload in ("grad", "pipeline"):
+    if workload in ("grad", "graddiv", "pipeline"):
         J, D, u = rng.random((3, 3, E)), rng.random((3, NP, NP)), rng.random((E, NP))
         out = np.empty((3, E, NP))
         fn = lambda: lib_native.oracle_grad3d_hoisted(J, D, u, out, E, NP)  # noqa: E731
@@ -133,16 +134,18 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="grad", choices=["grad", "div", "facemass", "pipeline"])
+    ap.add_argument("--workload", default="grad", choices=["grad", "div", "facemass", "graddiv", "pipeline"])
     ap.add_argument("--elems-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
     args = ap.parse_args()
 
     import torch
 
     import feinsum_amd as f
-    from feinsum_amd import measure, parallel
+    from feinsum_amd import measure, operator, parallel
 
     info = parallel.init_distributed()
     if info.world_size != args.gpus:
@@ -155,35 +158,33 @@ def main() -> None:
     E = args.elems_per_gpu
 
     exprs = _einsums()[args.workload]
-    bound, outs_all, flops_step, bytes_step = [], [], 0.0, 0.0
+    stages, out_dicts, outs_all, flops_step, bytes_step, shared = [], [], [], 0.0, 0.0, {}
     for k, expr in enumerate(exprs):
         dev = _device_inputs(expr, E, device, seed=1000 * info.rank + k)
+        for name in ("J", "R"):          # div and grad of one operator share J and D
+            if name in dev:
+                dev[name] = shared.setdefault(name, dev[name])
         outs = measure.generate_out_arrays(q, expr, E)
-        _, b, o = measure._bind(expr, q, dev, outs, args.variant)
-        bound.append(b)
-        outs_all += o
+        stages.append((expr, dev))
+        out_dicts.append(outs)
+        outs_all += list(outs.values())
         flops_step += f.count_ops(expr, long_dim_length=E)
         bytes_step += measure._get_footprint_gbytes(expr, E) * 1e9
+    if len(exprs) > 1:                   # J and D counted once
+        bytes_step -= 8.0 * (9 * E + 3 * NP * NP)
+    op = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse)
 
     s = q.stream_ptr
     for _ in range(args.warmup):
-        for b in bound:
-            b.launch(s)
+        op.launch(s)
     torch.cuda.synchronize(device)
     parallel.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    if len(bound) == 1:
-        kernel_s = bound[0].time_batch(args.steps, s)          # HIP events on the launch stream
+    if len(op.launches) == 1 and hasattr(op.launches[0], "time_batch"):
+        kernel_s = op.launches[0].time_batch(args.steps, s)    # HIP events on the launch stream
     else:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(q.stream)
-        for _ in range(args.steps):
-            for b in bound:
-                b.launch(s)
-        ev1.record(q.stream)
-        ev1.synchronize()
-        kernel_s = ev0.elapsed_time(ev1) * 1e-3
+        kernel_s = op.time_batch(args.steps, s)                # same, through torch's event objects
     torch.cuda.synchronize(device)
     parallel.barrier()
     torch.cuda.synchronize(device)
@@ -226,9 +227,10 @@ def main() -> None:
                 "workload": {"grad": "configs[1]: grad xre,rij,ej->xei p=4 (Np=35), 1e6 elements per GPU",
                              "div": "div xre,rij,xej->ei p=4, 1e6 elements per GPU",
                              "facemass": "configs[3]: face-mass ef,fij,fej->ei x4 p=4, 1e6 elements per GPU",
+                             "graddiv": "configs[2]: div xre,rij,xej->ei + grad sharing J and D, p=4, 1e6 elements per GPU",
                              "pipeline": "configs[4]: div + grad + face-mass x4, 1e6 elements per GPU"}[args.workload],
                 "elements_per_gpu": E, "parallelism": f"element-sharded x{n}, no data-path collective",
-                "variant": args.variant, "device": q.device.name,
+                "variant": args.variant, "device": q.device.name, "launches_per_step": list(op.entry_points),
             },
             "per_gpu_gflops": round(value / n, 1),
             "frac_of_min_roofline": round(value / n / roof_gflops, 4),

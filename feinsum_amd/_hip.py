@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
     "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
     "fe_grad3d_batched_f64", "fe_div3d_batched_f64",
-    "fe_graddiv3d_f64",
+    "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
 )
@@ -113,6 +113,9 @@ def load_library() -> C.CDLL:
                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_graddiv3d_f64.restype = C.c_int
     lib.fe_graddiv3d_f64.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_waveop3d_f64.restype = C.c_int
+    lib.fe_waveop3d_f64.argtypes = [C.c_void_p] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                       C.c_int64] + [C.c_int32] * 6 + [C.c_void_p]
     lib.fe_facemass_f64.restype = C.c_int
     lib.fe_facemass_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
@@ -207,6 +210,17 @@ def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: i
               Np: int, variant=None, stream: int = 0) -> None:
     check(load_library().fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np,
                                           variant_code(variant), stream))
+
+
+def waveop3d(J: int, D: int, u_grad: int, grad_out: int, v_div: int, div_out: int, Jface: int, R: int,
+             f: Sequence[int], lift: Sequence[int], E: int, Np: int, nf: int, Nfp: int,
+             fm_layout_flags: int = 0, variant=None, stream: int = 0) -> None:
+    """div(v), grad(u) and the lift of ``len(f)`` face fields in one persistent launch."""
+    if len(f) != len(lift):
+        raise InvalidParameterError("waveop: need as many lift outputs as face fields")
+    check(load_library().fe_waveop3d_f64(J, D, u_grad, grad_out, v_div, div_out, Jface, R,
+                                         _ptr_array(f), _ptr_array(lift), E, Np, nf, Nfp, len(f),
+                                         fm_layout_flags, variant_code(variant), stream))
 
 
 def facemass(J: int, R: int, v: Sequence[int], out: Sequence[int], E: int, Np: int, nf: int,

@@ -124,6 +124,25 @@ __device__ __forceinline__ void stage_operator(const double* __restrict__ g, dou
     }
 }
 
+// The same through the LDS-DMA path: N doubles from g to the LDS byte address lds (wave-uniform),
+// by the four waves of a 256-thread block.  Nothing passes through registers and the compiler
+// never waits on these loads, so the caller can queue further loads behind them and wait with a
+// counted vmcnt (loads return in order) before the block barrier that publishes the copy.
+template <int N>
+__device__ __forceinline__ void stage_operator_dma(const double* __restrict__ g, unsigned lds, int wave,
+                                                   int lane) {
+    constexpr int kChunks = N / 2;                       // 16-byte chunks
+    constexpr int kInstr = (kChunks + 255) / 256;        // per wave
+    const char* gb = reinterpret_cast<const char*>(g);
+#pragma unroll
+    for (int c = 0; c < kInstr; ++c) {
+        const int q0 = (c * 4 + wave) * 64;              // first chunk of this wave's instruction
+        if (q0 + lane < kChunks) glds16(gb + (q0 + lane) * 16, lds + q0 * 16);
+    }
+    if ((N & 1) && wave == 0 && lane < 2)                // odd N: the last double as two dwords
+        glds4(gb + (N - 1) * 8 + lane * 4, lds + (N - 1) * 8);
+}
+
 // Tried and rejected for balancing ACROSS CUs (a few CUs finish ~10 % late): tile tickets from
 // global atomic counters.  One counter retires only ~88 atomics/us (the kernels consume ~300
 // tiles/us); eight per-XCD counters with the ticket taken one or two iterations ahead still

@@ -64,9 +64,9 @@ struct DivGeom {
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
 template <int NP, int M, int kDbg = 0, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
-    int64_t nTiles, int opT, int jes) {
+__device__ __forceinline__ void div3d_mfma_body(
+    const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
+    int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
     using G = DivGeom<NP, M, MODE>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
-    const int64_t stride = (int64_t)gridDim.x * G::WAVES;
+    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     // nb fields share J and D ('xre,rij,xej->ei' x nb: tuning/impls/batched_xre_rij_xej_to_ei.py):
     // the wave walks (tile, field) units, field fastest; J is loaded with the first field of a
     // tile and stays in LDS until the last field's B fragments are built.
@@ -131,12 +131,12 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
             if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     };
-    int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
+    int64_t tile = (int64_t)bid * G::WAVES + wave;
     bool first = true;
-    if (tile < nTiles && !(kDbg & 8)) issue_loads(tile, 0, true);
-    const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
+    if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+    const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
-    while (tile < nTiles) {
+    while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
         const int64_t e0 = tile * G::TEL;
         double* const out = field_out(P, fk);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
             for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
-        if (nt < nTiles && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
+        if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
 
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -242,6 +242,13 @@ __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
         fk = nk;
         tile = nt;
     }
+}
+
+template <int NP, int M, int kDbg = 0, int MODE = 0>
+__global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
+    int64_t nTiles, int opT, int jes) {
+    div3d_mfma_body<NP, M, kDbg, MODE>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -82,10 +82,11 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
     }
 }
 
+// bid / nblk: see grad3d_mfma_body.
 template <int NP, int NFP, int M, int NB>
-__global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
-    int64_t nTiles, int jfe, int rlayout) {
+__device__ __forceinline__ void facemass_mfma_body(
+    const double* __restrict__ J, const double* __restrict__ R, const FieldPtrs& P, int64_t E,
+    int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
     using G = FmGeom<NP, NFP, M>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
 
     const unsigned lds_v0 = lds_addr_uniform(L->v[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
-    const int64_t stride = (int64_t)gridDim.x * G::WAVES;
-    const int64_t first = (int64_t)blockIdx.x * G::WAVES + wave;
-    if (first >= nTiles) return;
+    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
+    const int64_t first = (int64_t)bid * G::WAVES + wave;
+    if (first >= tEnd) return;
 
     // prologue: units 0 and 1 of the first tile
     fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
@@ -146,15 +147,15 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
     double jv[M][G::KS];
-    const bool younger_half = blockIdx.x >= (gridDim.x + 1) / 2;
+    const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0;
-    for (int64_t tile = first; tile < nTiles; tile += stride) {
+    for (int64_t tile = first; tile < tEnd; tile += stride) {
         balance_priority(younger_half, iteration++);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             // ---- wait for this unit's loads; younger ops: S(m-2), L(m+1), S(m-1)
             const bool next_is_tile_start = (k + 1 == NB);
-            const bool has_next = !next_is_tile_start || (tile + stride < nTiles);
+            const bool has_next = !next_is_tile_start || (tile + stride < tEnd);
             if (warm && has_next) {
                 if (next_is_tile_start) wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS + G::J_INSTR>();
                 else wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS>();
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
             {
                 const int k2 = (k + 2) % NB;   // folds after unrolling
                 const int64_t tile2 = tile + stride * ((k + 2) / NB);
-                if (tile2 < nTiles) {
+                if (tile2 < tEnd) {
                     if (k2 == 0)
                         fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[k2], E, tile2, lane,
                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
@@ -244,6 +245,13 @@ __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
             slot ^= 1;
         }
     }
+}
+
+template <int NP, int NFP, int M, int NB>
+__global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
+    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
+    int64_t nTiles, int jfe, int rlayout) {
+    facemass_mfma_body<NP, NFP, M, NB>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -60,15 +60,22 @@ struct GradGeom {
     static constexpr int LOADS = U_INSTR + J_INSTR;    // vector-memory ops per (tile, field) unit: loads
                                                        // (J only with the first field of a tile) ...
     static constexpr int STORES = 3 * M * SUB_INSTR;   // ... and stores
-    struct WaveLds {
+    struct WaveLds {             // input side, one per wave from the start of the block's LDS
         double u[2][TILE_D];     // prefetch double buffer
-        double o[2][SUB_D];      // output transposition buffers, alternating
         double j[2][9 * TEL];    // J[x*3+r][e0 + 0..TEL-1], double buffered (by tile)
+    };
+    struct WaveOut {             // output side, one per wave behind the four WaveLds
+        double o[2][SUB_D];      // output transposition buffers, alternating
     };
     static constexpr int WAVES = 4;
     static constexpr int OP_D = 3 * NP * NP;           // operator doubles (staged once per block)
-    static constexpr int LDS_BYTES =
-        (int)sizeof(WaveLds) * WAVES > OP_D * 8 ? (int)sizeof(WaveLds) * WAVES : OP_D * 8;
+    // The operator is staged over the OUTPUT buffers, which nobody needs before the first
+    // tile's stage 2: the input buffers are free from the first instruction, so the first two
+    // tiles stream in while the prologue runs.
+    static constexpr int IN_BYTES = (int)sizeof(WaveLds) * WAVES;
+    static constexpr int OUT_BYTES = (int)sizeof(WaveOut) * WAVES;
+    static constexpr int OP_BYTES = (OP_D * 8 + 15) / 16 * 16;
+    static constexpr int LDS_BYTES = IN_BYTES + (OUT_BYTES > OP_BYTES ? OUT_BYTES : OP_BYTES);
     static_assert(4 * TG >= NP, "row permutation must cover every i");
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
@@ -117,10 +124,12 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 // nb: fields per launch ('xre,rij,ej->xei' x NB sharing J and D: tuning/impls/
 // batched_xre_rij_ej_to_xei.py): J is loaded once per tile and serves all nb fields;
 // the wave walks (tile, field) units, field fastest.
+// bid / nblk: this block's index and the number of blocks walking the tiles (blockIdx.x /
+// gridDim.x for the plain kernel; the fused launches of fe_fused.h run several bodies in turn).
 template <int NP, int M, int kDbg = 0>
-__global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
-    int64_t nTiles, int opT) {
+__device__ __forceinline__ void grad3d_mfma_body(
+    const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
+    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk) {
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,14 +139,40 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;
+    typename G::WaveOut* LO = reinterpret_cast<typename G::WaveOut*>(smem + G::IN_BYTES) + wave;
     const int n = lane & 15, g = lane >> 4;
+    constexpr bool kNT = (kDbg & 16) == 0;
 
-    // ---- A fragments from the LDS-staged operator
+    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
+    int64_t tile = (int64_t)bid * G::WAVES + wave;
+
+    // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
+    stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
+    bool pre = false;   // unit 1 already requested
+    if (tile < tEnd && !(kDbg & 8)) {
+        grad_issue_u<NP, M, kNT>(P.v[0], tile, lane, lds_addr_uniform(L->u[0]));
+        grad_issue_j<NP, M>(J, E, tile, lane, lds_addr_uniform(L->j[0]));
+        if (nb > 1) {
+            grad_issue_u<NP, M, kNT>(P.v[1], tile, lane, lds_addr_uniform(L->u[1]));
+            pre = true;
+            wait_vmcnt<G::LOADS + G::U_INSTR>();
+        } else if (tile + stride < tEnd) {
+            grad_issue_u<NP, M, kNT>(P.v[0], tile + stride, lane, lds_addr_uniform(L->u[1]));
+            grad_issue_j<NP, M>(J, E, tile + stride, lane, lds_addr_uniform(L->j[1]));
+            pre = true;
+            wait_vmcnt<2 * G::LOADS>();
+        } else {
+            wait_vmcnt<G::LOADS>();
+        }
+    } else {
+        wait_vmcnt<0>();
+    }
+    __syncthreads();
+
+    // ---- A fragments from the staged operator
     double afrag[G::RT][G::KS];
     {
-        double* dl = reinterpret_cast<double*>(smem);
-        stage_operator<G::OP_D>(D, dl);
-        __syncthreads();
+        const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
         const int gp = n & 3, q = n >> 2;
 #pragma unroll
         for (int t = 0; t < G::RT; ++t) {
@@ -151,25 +186,18 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
                 afrag[t][ks] = ok ? dl[opT ? (r * NP + jc) * NP + ic : (r * NP + ic) * NP + jc] : 0.0;
             }
         }
-        __syncthreads();
+        __syncthreads();   // the staging area becomes the waves' output buffers
     }
 
-    const int64_t stride = (int64_t)gridDim.x * G::WAVES;
-    int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
     int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
-    constexpr bool kNT = (kDbg & 16) == 0;
-    if (tile < nTiles && !(kDbg & 8)) {
-        grad_issue_u<NP, M, kNT>(P.v[0], tile, lane, lds_addr_uniform(L->u[0]));
-        grad_issue_j<NP, M>(J, E, tile, lane, lds_addr_uniform(L->j[0]));
-    }
 #ifdef FE_EXPERIMENTS
     unsigned long long c0 = 0, r0 = 0;
     if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
-    const bool younger_half = !(kDbg & 64) && blockIdx.x >= (gridDim.x + 1) / 2;
+    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
-    while (tile < nTiles) {
+    while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
         // Vector-memory ops in issue order: L(unit) S(previous unit) L(next unit) | wait L(unit).
         // The stores of the previous unit and the loads of the next one are younger than this
@@ -179,10 +207,10 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
         const int nk = next_new_tile ? 0 : fk + 1;
         if (kDbg & 8) {
             wait_vmcnt<0>();
-        } else if (nt < nTiles) {
-            grad_issue_u<NP, M, kNT>(field_in(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
+        } else if (nt < tEnd) {
+            if (!pre) grad_issue_u<NP, M, kNT>(field_in(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
             if (next_new_tile) {
-                grad_issue_j<NP, M>(J, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
+                if (!pre) grad_issue_j<NP, M>(J, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
                 if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
                 else wait_vmcnt<G::LOADS + G::STORES>();
             } else {
@@ -194,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
             else wait_vmcnt<G::STORES>();
         }
         first = false;
+        pre = false;
 
         const double* ut = L->u[ub];
         const double* jt = L->j[jbuf];
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
             // ---- stage 2 + transposed store, plane by plane
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                double* ob = L->o[(m * 3 + x) & 1];
+                double* ob = LO->o[(m * 3 + x) & 1];
                 const double j0 = jt[(x * 3 + 0) * G::TEL + 16 * m + n];
                 const double j1 = jt[(x * 3 + 1) * G::TEL + 16 * m + n];
                 const double j2 = jt[(x * 3 + 2) * G::TEL + 16 * m + n];
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
 #ifdef FE_EXPERIMENTS
     if ((kDbg & 32) && lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-        const int w = blockIdx.x * G::WAVES + wave;
+        const int w = bid * G::WAVES + wave;
         if (w < 4096) {
             fe_dbg_stamps[w][0] = t_entry; fe_dbg_stamps[w][1] = r0; fe_dbg_stamps[w][2] = t_end;
             const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
@@ -274,6 +303,13 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
         if (w == 0) { fe_dbg_clock[0] = __builtin_amdgcn_s_memtime() - c0; fe_dbg_clock[1] = t_end - r0; }
     }
 #endif
+}
+
+template <int NP, int M, int kDbg = 0>
+__global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
+    int64_t nTiles, int opT) {
+    grad3d_mfma_body<NP, M, kDbg>(J, D, P, nb, E, nTiles, opT, blockIdx.x, gridDim.x);
 }
 
 

@@ -14,6 +14,7 @@
 #include "fe_div.h"
 #include "fe_einsum.h"
 #include "fe_facemass.h"
+#include "fe_fused.h"
 #include "fe_generic.h"
 #include "fe_grad.h"
 
@@ -185,8 +186,9 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     fe::FieldPtrs P = {};
     P.v[0] = u;
     P.out[0] = out;
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
-                       G::LDS_BYTES, s, J, D, P, 1, E, nTiles, opT, jes);
+    const unsigned grid = persistent_grid(nTiles, G::WAVES);
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, P, 1,
+                       E, nTiles, opT, jes);
     return FE_OK;
 }
 
@@ -197,8 +199,9 @@ int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64
     static PerDeviceOnce once;
     const int attr_rc = once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
-    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB>), dim3(persistent_grid(nTiles, G::WAVES)),
-                       dim3(256), G::LDS_BYTES, s, J, R, P, E, nTiles, jfe, rifj);
+    const unsigned grid = persistent_grid(nTiles, G::WAVES);
+    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, R,
+                       P, E, nTiles, jfe, rifj);
     return FE_OK;
 }
 
@@ -222,6 +225,60 @@ int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, 
         }
     }
     return fail(FE_EINVAL, "face-mass: internal field grouping error (nb=%d)", nb);
+}
+
+// div then grad in one persistent launch (full tiles only; e_done_* report what was covered)
+template <int NP, int MG, int MD>
+int launch_graddiv(const double* J, const double* D, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd,
+                   int64_t E, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
+    using GG = fe::GradGeom<NP, MG>;
+    using GD = fe::DivGeom<NP, MD>;
+    using G = fe::GradDivGeom<NP, MG, MD>;
+    const int64_t nTilesG = E / GG::TEL, nTilesD = E / GD::TEL;
+    *e_done_g = nTilesG * GG::TEL;
+    *e_done_d = nTilesD * GD::TEL;
+    if (nTilesG == 0 && nTilesD == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::graddiv3d_mfma_kernel<NP, MG, MD>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
+    const unsigned grid = persistent_grid(nTiles, 4);
+    hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, Pg,
+                       Pd, E, nTilesG, nTilesD, 0);
+    return FE_OK;
+}
+
+// div, grad and face-mass x nb (2..4) in one persistent launch (full tiles only)
+template <int NP, int NFP, int MG, int MD, int MF, int NB>
+int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd,
+                     const fe::FieldPtrs& Pf, hipStream_t s) {
+    using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
+    static PerDeviceOnce once;
+    const int attr_rc =
+        once.run([] { return set_max_lds(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    int64_t nTiles = a.nTilesG > a.nTilesD ? a.nTilesG : a.nTilesD;
+    if (a.nTilesF > nTiles) nTiles = a.nTilesF;
+    hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>), dim3(persistent_grid(nTiles, 4)),
+                       dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
+    return FE_OK;
+}
+
+template <int NP, int NFP, int MG, int MD, int MF>
+int launch_waveop(fe::WaveOpArgs a, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd, const fe::FieldPtrs& Pf,
+                  int nb, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
+    a.nTilesG = a.E / (16 * MG);
+    a.nTilesD = a.E / (16 * MD);
+    a.nTilesF = a.E / (16 * MF);
+    *e_done_g = a.nTilesG * 16 * MG;
+    *e_done_d = a.nTilesD * 16 * MD;
+    if (a.nTilesG == 0 && a.nTilesD == 0 && a.nTilesF == 0) return FE_OK;
+    switch (nb) {
+        case 2: return launch_waveop_nb<NP, NFP, MG, MD, MF, 2>(a, Pg, Pd, Pf, s);
+        case 3: return launch_waveop_nb<NP, NFP, MG, MD, MF, 3>(a, Pg, Pd, Pf, s);
+        case 4: return launch_waveop_nb<NP, NFP, MG, MD, MF, 4>(a, Pg, Pd, Pf, s);
+        default: return fail(FE_EINVAL, "waveop: internal field count error (nb=%d)", nb);
+    }
 }
 
 struct FmChoice { int max_group, tel; };
@@ -437,15 +494,44 @@ int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* 
 int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, const double* v_div,
                      double* grad_out, double* div_out, int64_t E, int32_t Np, int32_t variant,
                      void* stream) {
-    // Two launches back to back on one stream: J (72 B/element) and D stay in
-    // L2 / Infinity Cache between them only for small E; see DESIGN.md.
-    if (int rc = fe_grad3d_f64(J, D, u_grad, grad_out, E, Np, variant, stream)) return rc;
-    return fe_div3d_f64(J, D, v_div, div_out, E, Np, variant, stream);
+    if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
+    if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "graddiv: unknown variant %d", variant);
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    if (variant == FE_VARIANT_GENERIC || !mfma_ok) {
+        // two launches back to back on the stream
+        if (int rc = fe_div3d_f64(J, D, v_div, div_out, E, Np, variant, stream)) return rc;
+        return fe_grad3d_f64(J, D, u_grad, grad_out, E, Np, variant, stream);
+    }
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    fe::FieldPtrs Pg = {}, Pd = {};
+    Pg.v[0] = u_grad; Pg.out[0] = grad_out;
+    Pd.v[0] = v_div;  Pd.out[0] = div_out;
+    int64_t done_g = 0, done_d = 0;
+    int rc = FE_OK;
+    switch (Np) {   // same (Np, M) geometries as the separate launches
+        case 35: rc = launch_graddiv<35, 1, 1>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
+        case 20: rc = launch_graddiv<20, 2, 1>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
+        case 10: rc = launch_graddiv<10, 3, 3>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
+        default: rc = launch_graddiv<4, 5, 5>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
+    }
+    if (rc != FE_OK) return rc;
+    if (done_d < E)
+        hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - done_d, Np)), dim3(256), 0, s,
+                           J, D, v_div, div_out, E, Np, done_d, 0);
+    if (done_g < E)
+        hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - done_g, Np)), dim3(256), 0, s,
+                           J, D, u_grad, grad_out, E, Np, done_g, 0);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
 }
 
-int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
-                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
-                    int32_t layout_flags, int32_t variant, void* stream) {
+// tiles_done: the full MFMA tiles were covered by a fused launch; only the remainder is left
+static int facemass_impl(const double* J, const double* R, const double* const* v, double* const* out,
+                         int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                         int32_t layout_flags, int32_t variant, void* stream, bool tiles_done) {
     if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
     if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
         return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
@@ -491,7 +577,7 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
             P.v[k] = v[k0 + (k < nb ? k : 0)];
             P.out[k] = out[k0 + (k < nb ? k : 0)];
         }
-        if (nTiles > 0) {
+        if (nTiles > 0 && !tiles_done) {
             int rc = FE_OK;
             switch (Np) {   // wave tile = 16 M elements
                 case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
@@ -518,6 +604,65 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
     }
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
+}
+
+int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
+                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                    int32_t layout_flags, int32_t variant, void* stream) {
+    return facemass_impl(J, R, v, out, E, Np, nf, Nfp, b, layout_flags, variant, stream, false);
+}
+
+int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, double* grad_out,
+                    const double* v_div, double* div_out, const double* Jface, const double* R,
+                    const double* const* f, double* const* lift, int64_t E, int32_t Np, int32_t nf,
+                    int32_t Nfp, int32_t b, int32_t fm_layout_flags, int32_t variant, void* stream) {
+    FmChoice geo{0, 16};
+    const bool fused = variant != FE_VARIANT_GENERIC && fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
+                       b <= 4 && f && lift && E > 0 && !(fm_layout_flags & ~7);
+    if (!fused) {   // three launches (argument checks included)
+        if (int rc = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc;
+        return fe_facemass_f64(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream);
+    }
+    if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
+    if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "waveop: unknown variant %d", variant);
+    if (!Jface || !R) return fail(FE_EINVAL, "waveop: null device pointer");
+    uintptr_t bits = reinterpret_cast<uintptr_t>(Jface) | reinterpret_cast<uintptr_t>(R);
+    for (int k = 0; k < b; ++k) {
+        if (!f[k] || !lift[k]) return fail(FE_EINVAL, "waveop: null field pointer %d", k);
+        bits |= reinterpret_cast<uintptr_t>(f[k]) | reinterpret_cast<uintptr_t>(lift[k]);
+    }
+    if (bits & 7u) return fail(FE_EINVAL, "waveop: device pointers must be 8-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    fe::FieldPtrs Pg = {}, Pd = {}, Pf = {};
+    Pg.v[0] = u_grad; Pg.out[0] = grad_out;
+    Pd.v[0] = v_div;  Pd.out[0] = div_out;
+    for (int k = 0; k < fe::kMaxFields; ++k) {
+        Pf.v[k] = f[k < b ? k : 0];
+        Pf.out[k] = lift[k < b ? k : 0];
+    }
+    fe::WaveOpArgs a = {};
+    a.J = J; a.D = D; a.Jf = Jface; a.R = R; a.E = E;
+    a.jfe = (fm_layout_flags & FE_FM_J_FE) ? 1 : 0;
+    a.rlayout = ((fm_layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((fm_layout_flags & FE_FM_R_T) ? 2 : 0);
+    int64_t done_g = 0, done_d = 0;
+    int rc = FE_OK;
+    switch (Np) {   // the (Np, M) geometries of the three separate launches
+        case 35: rc = launch_waveop<35, 15, 1, 1, 1>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
+        case 20: rc = launch_waveop<20, 10, 2, 1, 1>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
+        case 10: rc = launch_waveop<10, 6, 3, 3, 2>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
+        default: rc = launch_waveop<4, 3, 5, 5, 4>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
+    }
+    if (rc != FE_OK) return rc;
+    if (done_d < E)
+        hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - done_d, Np)), dim3(256), 0, s,
+                           J, D, v_div, div_out, E, Np, done_d, 0);
+    if (done_g < E)
+        hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - done_g, Np)), dim3(256), 0, s,
+                           J, D, u_grad, grad_out, E, Np, done_g, 0);
+    FE_HIP_CHECK(hipGetLastError());
+    return facemass_impl(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream, true);
 }
 
 int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void* out,

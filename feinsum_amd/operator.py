@@ -1,0 +1,159 @@
+"""
+Several einsums of one DG operator evaluation as a single enqueue.
+
+The reference drives the whole 3-D wave operator from one description:
+``examples/wave_3d_p4_auto.py:16-63`` holds div(v), grad(u) and the lift of four
+face fields in one kernel, matches each tagged part against an einsum
+(``get_a_matched_einsum``, ``:69-71``) and applies that einsum's transform
+(``:119-139``); the parts stay separated by global barriers, i.e. they run one
+after the other.  None of them reads what another one writes.
+
+Here the description is a list of *stages* ``(BatchedEinsum, arrays)``.  Every
+stage is bound to its kernel family exactly as :func:`feinsum_amd.evaluate`
+does; stages that the library can run inside one persistent launch are then
+merged:
+
+* div + grad that share the geometry factors J and the operator D
+  (``fe_graddiv3d_f64``; BASELINE config 3),
+* div + grad + face-mass of 2..4 fields (``fe_waveop3d_f64``; config 5),
+
+and everything else is enqueued stage by stage in the order given.  Results do
+not depend on the merge: a merged launch runs the same per-tile arithmetic.
+"""
+
+from __future__ import annotations
+
+from types import MappingProxyType
+from typing import Any, List, Mapping, Optional, Sequence, Tuple
+
+from feinsum_amd import _hip
+from feinsum_amd.einsum import BatchedEinsum
+from feinsum_amd.family import FAMILY_DIV, FAMILY_FACEMASS, FAMILY_GRAD
+from feinsum_amd.measure import _bind, _FamilyLaunch
+
+StageT = Tuple[BatchedEinsum, Mapping[str, Any]]
+
+
+class _GradDivLaunch:
+    """div + grad in one launch (shared J and D)."""
+
+    entry_point = "fe_graddiv3d_f64"
+
+    def __init__(self, grad: _FamilyLaunch, div: _FamilyLaunch) -> None:
+        self._keep = (grad, div)
+        g, d = grad.groups[0], div.groups[0]
+        self.args = (g.J, g.D, g.u, d.u, g.out, d.out, g.E, g.Np, grad.variant)
+
+    def launch(self, stream_ptr: int) -> None:
+        _hip.check(_hip.load_library().fe_graddiv3d_f64(*self.args, stream_ptr))
+
+
+class _WaveOpLaunch:
+    """div + grad + face-mass in one launch."""
+
+    entry_point = "fe_waveop3d_f64"
+
+    def __init__(self, grad: _FamilyLaunch, div: _FamilyLaunch, lift: _FamilyLaunch) -> None:
+        self._keep = (grad, div, lift)
+        g, d, m = grad.groups[0], div.groups[0], lift.groups[0]
+        self.args = (g.J, g.D, g.u, g.out, d.u, d.out, m.J, m.D, m.v, m.outs, g.E, g.Np, m.nf, m.Nfp,
+                     m.b, m.layout_flags, grad.variant)
+
+    def launch(self, stream_ptr: int) -> None:
+        _hip.check(_hip.load_library().fe_waveop3d_f64(*self.args, stream_ptr))
+
+
+def _single_plain_group(b: Any, family: int) -> bool:
+    return (isinstance(b, _FamilyLaunch) and b.plan.family == family and len(b.groups) == 1
+            and (family == FAMILY_FACEMASS or (b.groups[0].b == 1 and b.plan.layout_flags == 0)))
+
+
+def _merge(bound: List[Any]) -> List[Any]:
+    """Replace the first mergeable (div, grad[, face-mass]) set by its fused launch."""
+    grads = [b for b in bound if _single_plain_group(b, FAMILY_GRAD)]
+    for g in grads:
+        gp = g.groups[0]
+        for d in bound:
+            if not _single_plain_group(d, FAMILY_DIV):
+                continue
+            dp = d.groups[0]
+            if (dp.J, dp.D, dp.E, dp.Np, d.variant) != (gp.J, gp.D, gp.E, gp.Np, g.variant):
+                continue
+            lift = next((m for m in bound if _single_plain_group(m, FAMILY_FACEMASS)
+                         and 2 <= m.groups[0].b <= 4 and m.variant == g.variant
+                         and (m.groups[0].E, m.groups[0].Np) == (gp.E, gp.Np)), None)
+            fused = _WaveOpLaunch(g, d, lift) if lift is not None else _GradDivLaunch(g, d)
+            gone = {id(g), id(d)} | ({id(lift)} if lift is not None else set())
+            first = min(k for k, b in enumerate(bound) if id(b) in gone)
+            rest = [b for b in bound if id(b) not in gone]
+            return rest[:first] + [fused] + _merge(rest[first:])
+    return bound
+
+
+class BoundOperator:
+    """The stages of an operator bound to device arrays; ``launch`` enqueues all of them."""
+
+    def __init__(self, queue: Any, launches: List[Any], outputs: List[Mapping[str, Any]]) -> None:
+        self.queue, self.launches, self.outputs = queue, launches, outputs
+
+    @property
+    def entry_points(self) -> Tuple[str, ...]:
+        """C entry point behind every enqueue, in order (one per launch group)."""
+        names: List[str] = []
+        for b in self.launches:
+            if hasattr(b, "entry_point"):
+                names.append(b.entry_point)
+            elif isinstance(b, _FamilyLaunch):
+                names += [f"fe_{b.plan.name}"] * len(b.groups)
+            else:
+                names += ["fe_einsum_generic"] * len(b.launches)
+        return tuple(names)
+
+    def launch(self, stream_ptr: Optional[int] = None) -> None:
+        s = self.queue.stream_ptr if stream_ptr is None else stream_ptr
+        for b in self.launches:
+            b.launch(s)
+
+    def time_batch(self, n: int, stream_ptr: Optional[int] = None) -> float:
+        """Seconds for *n* evaluations of the whole operator (events on the launch stream)."""
+        import torch
+
+        s = self.queue.stream_ptr if stream_ptr is None else stream_ptr
+        stream = torch.cuda.ExternalStream(s) if s else torch.cuda.current_stream()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(stream)
+        for _ in range(n):
+            self.launch(s)
+        t1.record(stream)
+        t1.synchronize()
+        return t0.elapsed_time(t1) * 1e-3
+
+
+def bind_operator(stages: Sequence[StageT], cq: Any, *,
+                  out_dicts: Optional[Sequence[Optional[Mapping[str, Any]]]] = None,
+                  transform: Any = None, fuse: bool = True) -> BoundOperator:
+    """Bind every stage (shape / dtype / device checks as in ``evaluate``) and merge what can share a launch."""
+    if out_dicts is not None and len(out_dicts) != len(stages):
+        raise ValueError("out_dicts: need one entry (or None) per stage")
+    queue, bound, outputs = None, [], []
+    for k, (expr, arrays) in enumerate(stages):
+        q, b, outs = _bind(expr, cq, arrays, None if out_dicts is None else out_dicts[k], transform)
+        queue = queue or q
+        bound.append(b)
+        outputs.append(MappingProxyType(dict(zip(expr.output_names, outs))))
+    return BoundOperator(queue, _merge(bound) if fuse else bound, outputs)
+
+
+def evaluate_operator(stages: Sequence[StageT], cq: Any, *,
+                      out_dicts: Optional[Sequence[Optional[Mapping[str, Any]]]] = None,
+                      transform: Any = None, fuse: bool = True, wait: bool = False) -> List[Mapping[str, Any]]:
+    """Enqueue all stages; returns one ``{"_fe_out": tensor, ...}`` mapping per stage."""
+    import torch
+
+    op = bind_operator(stages, cq, out_dicts=out_dicts, transform=transform, fuse=fuse)
+    if op.queue is not None:
+        with torch.cuda.device(op.queue.torch_device):
+            op.launch()
+        if wait:
+            op.queue.finish()
+    return op.outputs

@@ -138,12 +138,26 @@ int fe_div3d_batched_f64(const double* J, const double* D,
                          int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                          int32_t variant, void* stream);
 
-/* fused grad + div sharing J and D (BASELINE config 3):
+/* fused grad + div sharing J and D (BASELINE config 3), one persistent launch:
  *   grad_out[3][E][Np] from u_grad[E][Np];  div_out[E][Np] from v_div[3][E][Np] */
 int fe_graddiv3d_f64(const double* J, const double* D,
                      const double* u_grad, const double* v_div,
                      double* grad_out, double* div_out,
                      int64_t E, int32_t Np, int32_t variant, void* stream);
+
+/* The three einsums of one DG wave operator evaluation -- div(v), grad(u) and the lift of b
+ * face fields -- in ONE persistent launch (examples/wave_3d_p4_auto.py:16-63 runs them as
+ * three kernels separated by global barriers; they share no data except J and D).
+ * Arguments as in fe_graddiv3d_f64 and fe_facemass_f64 (Jface, R, f, lift, fm_layout_flags).
+ * Single launch for the tetrahedral orders p = 1..4 with 2 <= b <= 4; anything else runs
+ * as fe_graddiv3d_f64 followed by fe_facemass_f64. */
+int fe_waveop3d_f64(const double* J, const double* D,
+                    const double* u_grad, double* grad_out,
+                    const double* v_div, double* div_out,
+                    const double* Jface, const double* R,
+                    const double* const* f, double* const* lift,
+                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                    int32_t fm_layout_flags, int32_t variant, void* stream);
 
 /* face-mass (lift), b fields sharing J and R:
  *   out_k[e,i] = sum_{f,j} J[e,f] * R[f,i,j] * v_k[f,e,j],  k = 0..b-1

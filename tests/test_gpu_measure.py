@@ -92,6 +92,33 @@ def test_evaluate_argument_errors():
         f.evaluate(expr, 0, {**dev, "u": torch.zeros((65, 35), dtype=torch.float64, device="cuda")})
 
 
+@pytest.mark.parametrize("Np", [4, 10, 20, 35, 56])
+@pytest.mark.parametrize("E", [1, 15, 80, 4099, 20011])
+def test_fused_graddiv_single_launch(Np, E):
+    # div then grad in one persistent launch (BASELINE config 3); tails and orders without an
+    # MFMA geometry go through the generic kernels
+    import torch
+
+    from oracle import np_oracle
+
+    rng = np.random.default_rng(Np + E)
+    J, D = rng.random((3, 3, E)), rng.random((3, Np, Np))
+    u, v = rng.random((E, Np)), rng.random((3, E, Np))
+    dJ, dD, du, dv = (torch.from_numpy(a).cuda() for a in (J, D, u, v))
+    og = torch.full((3, E, Np), float("nan"), dtype=torch.float64, device="cuda")
+    od = torch.full((E, Np), float("nan"), dtype=torch.float64, device="cuda")
+    _hip.graddiv3d(dJ.data_ptr(), dD.data_ptr(), du.data_ptr(), dv.data_ptr(), og.data_ptr(),
+                   od.data_ptr(), E, Np, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np_oracle.max_rel_err(og.cpu().numpy(), np.einsum("xre,rij,ej->xei", J, D, u, optimize="optimal")) <= 1e-12
+    assert np_oracle.max_rel_err(od.cpu().numpy(), np.einsum("xre,rij,xej->ei", J, D, v, optimize="optimal")) <= 1e-12
+    # bitwise the separate launches
+    og2, od2 = torch.empty_like(og), torch.empty_like(od)
+    _hip.grad3d(dJ.data_ptr(), dD.data_ptr(), du.data_ptr(), og2.data_ptr(), E, Np)
+    _hip.div3d(dJ.data_ptr(), dD.data_ptr(), dv.data_ptr(), od2.data_ptr(), E, Np)
+    assert torch.equal(og, og2) and torch.equal(od, od2)
+
+
 def test_fused_graddiv_and_time_launches():
     import torch
 
@@ -117,6 +144,42 @@ def test_fused_graddiv_and_time_launches():
     assert 0 < ms < 100
     name, pf, pb = _hip.device_info(0)
     assert pf == pytest.approx(78643.2, rel=0.05) and pb == 8000.0 and name
+
+
+@pytest.mark.parametrize("Np,Nfp", [(35, 15), (10, 6)])
+@pytest.mark.parametrize("E", [7, 4099])
+def test_wave_operator_single_launch(Np, Nfp, E):
+    """div(v), grad(u) and the lift of four face fields described as three einsums
+    (examples/wave_3d_p4_auto.py:16-63) run as ONE launch and match the oracle stage by stage."""
+    import torch
+
+    from oracle import np_oracle
+
+    exprs = [dg.div(Np), dg.grad(Np), dg.face_mass_ifj_fe(4, Np=Np, Nfp=Nfp)]
+    hosts = [generate_host_input_arrays(e, E, np_seed=k) for k, e in enumerate(exprs)]
+    hosts[1]["J"], hosts[1]["R"] = hosts[0]["J"], hosts[0]["R"]        # one geometry, one operator
+    devs = [{k: torch.from_numpy(v).cuda() for k, v in h.items()} for h in hosts]
+    devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+    stages = list(zip(exprs, devs))
+    op = f.bind_operator(stages, 0)
+    assert op.entry_points == ("fe_waveop3d_f64",)
+    outs = f.evaluate_operator(stages, 0, wait=True)
+    plain = f.evaluate_operator(stages, 0, fuse=False, wait=True)
+    for expr, host, out, ref_out in zip(exprs, hosts, outs, plain):
+        for name, row in zip(expr.output_names, expr.args):
+            ref = np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in row]])[0]
+            assert np_oracle.max_rel_err(out[name].cpu().numpy(), ref) <= 1e-12
+            assert torch.equal(out[name], ref_out[name])                # bitwise the separate launches
+
+    # what cannot share a launch is enqueued stage by stage
+    five = dg.face_mass(5, Np=Np, Nfp=Nfp)
+    h5 = generate_host_input_arrays(five, E, np_seed=5)
+    op = f.bind_operator(stages[:2] + [(five, {k: torch.from_numpy(v).cuda() for k, v in h5.items()})], 0)
+    assert op.entry_points[0] == "fe_graddiv3d_f64" and set(op.entry_points[1:]) == {"fe_facemass"}
+    own_j = dict(devs[1], J=devs[1]["J"].clone())
+    op = f.bind_operator([stages[0], (exprs[1], own_j)], 0)
+    assert op.entry_points == ("fe_div", "fe_grad")
+    assert op.time_batch(2) > 0
 
 
 def test_launchers_are_graph_capturable():

@@ -73,6 +73,7 @@ static int ab_main(int argc, char** argv) {
         a.u = to_dev(rnd((fam == "grad" ? 1 : 3) * E * Np, 3));
         double* o; CK(hipMalloc(&o, (fam == "grad" ? 3 : 1) * E * Np * 8)); a.out = o;
         family = fam == "grad" ? FE_FAMILY_GRAD : FE_FAMILY_DIV;
+        a.b = 1;
         flops = 7980.0 * E; bytes = 1192.0 * E;
     } else {
         a.J = to_dev(rnd(E * nf, 1)); a.D = to_dev(rnd(nf * Np * Nfp, 2));
@@ -170,6 +171,7 @@ static int abl_main(int argc, char** argv) {
         a.u = to_dev(rnd((fam == "grad" ? 1 : 3) * E * Np, 3));
         double* o; CK(hipMalloc(&o, (fam == "grad" ? 3 : 1) * E * Np * 8)); a.out = o;
         family = fam == "grad" ? FE_FAMILY_GRAD : FE_FAMILY_DIV;
+        a.b = 1;
         flops = 7980.0 * E; bytes = 1192.0 * E;
     } else {
         a.J = to_dev(rnd(E * nf, 1)); a.D = to_dev(rnd(nf * Np * Nfp, 2));
