@@ -25,7 +25,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MF
 EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
     "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
-    "fe_grad3d_batched_f64", "fe_div3d_batched_f64",
+    "fe_grad3d_batched_f64", "fe_div3d_batched_f64", "fe_gradplanes3d_f64",
     "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
@@ -44,6 +44,7 @@ class ArgPack(C.Structure):
         ("E", C.c_int64),
         ("Np", C.c_int32), ("nf", C.c_int32), ("Nfp", C.c_int32), ("b", C.c_int32),
         ("layout_flags", C.c_int32), ("variant", C.c_int32),
+        ("j3", C.POINTER(C.c_void_p)),
     ]
 
 
@@ -111,6 +112,10 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_gradplanes3d_f64.restype = C.c_int
+    lib.fe_gradplanes3d_f64.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_graddiv3d_f64.restype = C.c_int
     lib.fe_graddiv3d_f64.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_waveop3d_f64.restype = C.c_int
@@ -204,6 +209,16 @@ def div3d_batched(J: int, D: int, u: Sequence[int], out: Sequence[int], E: int, 
         raise InvalidParameterError("div: need as many outputs as fields")
     check(load_library().fe_div3d_batched_f64(J, D, _ptr_array(u), _ptr_array(out), E, Np, len(u),
                                               op_flags, variant_code(variant), stream))
+
+
+def gradplanes3d(J3: Sequence[int], D: int, u: Sequence[int], out: Sequence[Optional[int]], E: int,
+                 Np: int, variant=None, stream: int = 0, op_flags: int = 0) -> None:
+    """Rows of a batched 're,rij,ej->ei' sharing u and D: ``out[3k + x]`` from ``J3[x]`` and ``u[k]``
+    (``None`` = plane not wanted)."""
+    if len(J3) != 3 or len(out) != 3 * len(u):
+        raise InvalidParameterError("grad planes: need 3 J arrays and 3 output slots per field")
+    check(load_library().fe_gradplanes3d_f64(_ptr_array(J3), D, _ptr_array(u), _ptr_array(out), E, Np,
+                                             len(u), op_flags, variant_code(variant), stream))
 
 
 def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: int, E: int,

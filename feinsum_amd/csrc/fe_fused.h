@@ -35,11 +35,11 @@ struct GradDivGeom {
 
 template <int NP, int MG, int MD>
 __global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs Pg, FieldPtrs Pd,
+    const double* __restrict__ J, const double* __restrict__ D, GradFields Pg, FieldPtrs Pd,
     int64_t E, int64_t nTilesG, int64_t nTilesD, int opT) {
     div3d_mfma_body<NP, MD>(J, D, Pd, 1, E, nTilesD, opT, 0, blockIdx.x, gridDim.x);
     body_boundary();
-    grad3d_mfma_body<NP, MG>(J, D, Pg, 1, E, nTilesG, opT, blockIdx.x, gridDim.x);
+    grad3d_mfma_body<NP, MG>(Pg, D, 1, 3, E, nTilesG, opT, blockIdx.x, gridDim.x);
 }
 
 // div, grad and lift (face-mass x NB) of one time-step stage.
@@ -59,11 +59,11 @@ struct WaveOpArgs {
 };
 
 template <int NP, int NFP, int MG, int MD, int MF, int NB>
-__global__ __launch_bounds__(256, 2) void waveop3d_mfma_kernel(WaveOpArgs a, FieldPtrs Pg, FieldPtrs Pd,
+__global__ __launch_bounds__(256, 2) void waveop3d_mfma_kernel(WaveOpArgs a, GradFields Pg, FieldPtrs Pd,
                                                                FieldPtrs Pf) {
     div3d_mfma_body<NP, MD>(a.J, a.D, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x, gridDim.x);
     body_boundary();
-    grad3d_mfma_body<NP, MG>(a.J, a.D, Pg, 1, a.E, a.nTilesG, 0, blockIdx.x, gridDim.x);
+    grad3d_mfma_body<NP, MG>(Pg, a.D, 1, 3, a.E, a.nTilesG, 0, blockIdx.x, gridDim.x);
     body_boundary();
     facemass_mfma_body<NP, NFP, MF, NB>(a.Jf, a.R, Pf, a.E, a.nTilesF, a.jfe, a.rlayout, blockIdx.x,
                                         gridDim.x);

@@ -59,7 +59,8 @@ struct GradGeom {
     static constexpr int SUB_INSTR = (SUB_CHUNKS + 63) / 64;
     static constexpr int LOADS = U_INSTR + J_INSTR;    // vector-memory ops per (tile, field) unit: loads
                                                        // (J only with the first field of a tile) ...
-    static constexpr int STORES = 3 * M * SUB_INSTR;   // ... and stores
+    static constexpr int PLANE_STORES = M * SUB_INSTR; // ... and stores, per output plane
+    static constexpr int STORES = 3 * PLANE_STORES;
     struct WaveLds {             // input side, one per wave from the start of the block's LDS
         double u[2][TILE_D];     // prefetch double buffer
         double j[2][9 * TEL];    // J[x*3+r][e0 + 0..TEL-1], double buffered (by tile)
@@ -81,6 +82,40 @@ struct GradGeom {
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 };
 
+// Operands of a grad-type launch.  Output plane x of field k is
+//     out[k][x][e, i] = sum_r j[x][r, e] * (sum_j D[r, i, j] u[k][e, j])
+// with j[x] a [3][E] array.  grad 'xre,rij,ej->xei': j[x] = J + 3 x E and out[k][x] = out_k + x E Np.
+// A field may leave planes out (null pointer): the curl-type batch 're,rji,ej->ei' x 12 of
+// tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231 is six fields with two planes each
+// over three [3][E] arrays, so that D u is formed once per field and not once per output.
+// Every field of a launch has the same number of planes (nx).
+struct GradFields {
+    const double* j[3];
+    const double* u[kMaxFields];
+    double* out[kMaxFields][3];
+};
+
+__device__ __forceinline__ const double* grad_field_u(const GradFields& P, int k) {   // see field_in
+    const double* p = P.u[0];
+#pragma unroll
+    for (int q = 1; q < kMaxFields; ++q) p = (k == q) ? P.u[q] : p;
+    return p;
+}
+__device__ __forceinline__ double* grad_plane_out(const GradFields& P, int k, int x) {   // x: literal
+    double* p = P.out[0][x];
+#pragma unroll
+    for (int q = 1; q < kMaxFields; ++q) p = (k == q) ? P.out[q][x] : p;
+    return p;
+}
+
+// wait until at most BASE + nx * PER vector-memory operations are outstanding
+template <int BASE, int PER>
+__device__ __forceinline__ void wait_vmcnt_planes(int nx) {
+    if (nx == 3) wait_vmcnt<BASE + 3 * PER>();
+    else if (nx == 2) wait_vmcnt<BASE + 2 * PER>();
+    else wait_vmcnt<BASE + PER>();
+}
+
 template <int NP, int M, bool kNT = true>
 __device__ __forceinline__ void grad_issue_u(const double* __restrict__ u, int64_t tile, int lane,
                                              unsigned lds_u) {
@@ -94,17 +129,25 @@ __device__ __forceinline__ void grad_issue_u(const double* __restrict__ u, int64
         }
 }
 
-template <int NP, int M>
-__device__ __forceinline__ void grad_issue_j(const double* __restrict__ J, int64_t E, int64_t tile,
-                                             int lane, unsigned lds_j) {
+// kPlain: the planes are those of one 'xre,rij,ej->xei' (j[x] = j[0] + 3 x E, out[k][x] =
+// out[k][0] + x E Np, all three wanted) -- no per-lane pointer selects, no plane tests.
+template <int NP, int M, bool kPlain>
+__device__ __forceinline__ void grad_issue_j(const GradFields& P, int64_t E, int64_t tile, int lane,
+                                             unsigned lds_j) {
     using G = GradGeom<NP, M>;
-    const char* jb = reinterpret_cast<const char*>(J) + tile * (G::TEL * 8);
 #pragma unroll
     for (int c = 0; c < G::J_INSTR; ++c) {
-        const int q = c * 64 + lane;                      // chunk -> (row, column chunk)
+        const int q = c * 64 + lane;                      // chunk -> (row x*3 + r, column chunk)
         const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
-        if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS)
-            glds16(jb + ((int64_t)row * E) * 8 + col * 16, lds_j + c * 1024);
+        const double* jrow;
+        if (kPlain) {
+            jrow = P.j[0] + (int64_t)row * E;
+        } else {
+            const int x = row / 3, r = row - 3 * x;
+            jrow = (x == 0 ? P.j[0] : x == 1 ? P.j[1] : P.j[2]) + (int64_t)r * E;
+        }
+        const char* src = reinterpret_cast<const char*>(jrow + tile * G::TEL) + col * 16;
+        if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
     }
 }
 
@@ -126,10 +169,11 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 // the wave walks (tile, field) units, field fastest.
 // bid / nblk: this block's index and the number of blocks walking the tiles (blockIdx.x /
 // gridDim.x for the plain kernel; the fused launches of fe_fused.h run several bodies in turn).
-template <int NP, int M, int kDbg = 0>
+template <int NP, int M, int kDbg = 0, bool kPlain = true>
 __device__ __forceinline__ void grad3d_mfma_body(
-    const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
-    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk) {
+    const GradFields& P, const double* __restrict__ D, int nb, int nx_, int64_t E, int64_t nTiles, int opT,
+    const unsigned bid, const unsigned nblk) {
+    const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,15 +194,15 @@ __device__ __forceinline__ void grad3d_mfma_body(
     stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
     bool pre = false;   // unit 1 already requested
     if (tile < tEnd && !(kDbg & 8)) {
-        grad_issue_u<NP, M, kNT>(P.v[0], tile, lane, lds_addr_uniform(L->u[0]));
-        grad_issue_j<NP, M>(J, E, tile, lane, lds_addr_uniform(L->j[0]));
+        grad_issue_u<NP, M, kNT>(P.u[0], tile, lane, lds_addr_uniform(L->u[0]));
+        grad_issue_j<NP, M, kPlain>(P, E, tile, lane, lds_addr_uniform(L->j[0]));
         if (nb > 1) {
-            grad_issue_u<NP, M, kNT>(P.v[1], tile, lane, lds_addr_uniform(L->u[1]));
+            grad_issue_u<NP, M, kNT>(P.u[1], tile, lane, lds_addr_uniform(L->u[1]));
             pre = true;
             wait_vmcnt<G::LOADS + G::U_INSTR>();
         } else if (tile + stride < tEnd) {
-            grad_issue_u<NP, M, kNT>(P.v[0], tile + stride, lane, lds_addr_uniform(L->u[1]));
-            grad_issue_j<NP, M>(J, E, tile + stride, lane, lds_addr_uniform(L->j[1]));
+            grad_issue_u<NP, M, kNT>(P.u[0], tile + stride, lane, lds_addr_uniform(L->u[1]));
+            grad_issue_j<NP, M, kPlain>(P, E, tile + stride, lane, lds_addr_uniform(L->j[1]));
             pre = true;
             wait_vmcnt<2 * G::LOADS>();
         } else {
@@ -208,25 +252,29 @@ __device__ __forceinline__ void grad3d_mfma_body(
         if (kDbg & 8) {
             wait_vmcnt<0>();
         } else if (nt < tEnd) {
-            if (!pre) grad_issue_u<NP, M, kNT>(field_in(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
+            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
             if (next_new_tile) {
-                if (!pre) grad_issue_j<NP, M>(J, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
+                if (!pre) grad_issue_j<NP, M, kPlain>(P, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
                 if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
-                else wait_vmcnt<G::LOADS + G::STORES>();
+                else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
             } else {
                 if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
-                else wait_vmcnt<G::U_INSTR + G::STORES>();
+                else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
             }
         } else {
             if (first || (kDbg & 2)) wait_vmcnt<0>();
-            else wait_vmcnt<G::STORES>();
+            else wait_vmcnt_planes<0, G::PLANE_STORES>(nx);
         }
         first = false;
         pre = false;
 
         const double* ut = L->u[ub];
         const double* jt = L->j[jbuf];
-        double* const out = field_out(P, fk);
+        double* out_x[3];
+        out_x[0] = grad_plane_out(P, fk, 0);
+        out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
+        out_x[2] = kPlain ? out_x[0] + 2 * E * NP : grad_plane_out(P, fk, 2);
+        int obuf = 0;
         const int64_t e0 = tile * G::TEL;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -256,7 +304,9 @@ __device__ __forceinline__ void grad3d_mfma_body(
             // ---- stage 2 + transposed store, plane by plane
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                double* ob = LO->o[(m * 3 + x) & 1];
+                if (!kPlain && out_x[x] == nullptr) continue;   // plane not asked for (wave-uniform)
+                double* ob = LO->o[kPlain ? (m * 3 + x) & 1 : obuf];
+                obuf ^= 1;
                 const double j0 = jt[(x * 3 + 0) * G::TEL + 16 * m + n];
                 const double j1 = jt[(x * 3 + 1) * G::TEL + 16 * m + n];
                 const double j2 = jt[(x * 3 + 2) * G::TEL + 16 * m + n];
@@ -271,7 +321,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                     if (G::TG * 3 + k < NP || i < NP) ob[n * NP + i] = v;
                 }
                 wave_lds_fence();
-                double* op = out + ((int64_t)x * E + e0 + 16 * m) * NP;
+                double* op = out_x[x] + (e0 + 16 * m) * NP;
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int q = c * 64 + lane;
@@ -305,11 +355,10 @@ __device__ __forceinline__ void grad3d_mfma_body(
 #endif
 }
 
-template <int NP, int M, int kDbg = 0>
+template <int NP, int M, int kDbg = 0, bool kPlain = true>
 __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
-    int64_t nTiles, int opT) {
-    grad3d_mfma_body<NP, M, kDbg>(J, D, P, nb, E, nTiles, opT, blockIdx.x, gridDim.x);
+    GradFields P, const double* __restrict__ D, int nb, int nx, int64_t E, int64_t nTiles, int opT) {
+    grad3d_mfma_body<NP, M, kDbg, kPlain>(P, D, nb, nx, E, nTiles, opT, blockIdx.x, gridDim.x);
 }
 
 

@@ -98,7 +98,7 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
 }
 
 template <int NP, int M>
-int launch_grad(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E,
+int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, int nx, int64_t E,
                 int dbg, int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::GradGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
@@ -107,6 +107,7 @@ int launch_grad(const double* J, const double* D, const fe::FieldPtrs& P, int nb
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
         int rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+        if (rc == FE_OK) rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0, false>, G::LDS_BYTES);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
             set_max_lds(fe::grad3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
@@ -120,8 +121,13 @@ int launch_grad(const double* J, const double* D, const fe::FieldPtrs& P, int nb
     });
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
+    if (!plain) {   // general planes: per-plane geometry-factor and output pointers
+        hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, false>), g, b, G::LDS_BYTES, s, P, D, nb, nx, E, nTiles,
+                           opT);
+        return FE_OK;
+    }
 #define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT)
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, P, D, nb, nx, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
@@ -227,9 +233,61 @@ int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, 
     return fail(FE_EINVAL, "face-mass: internal field grouping error (nb=%d)", nb);
 }
 
+// 'xre,rij,ej->xei' operands as grad-type planes: j[x] = J[x], out[k][x] = out_k[x]
+fe::GradFields grad_fields(const double* J, const double* const* u, double* const* out, int nb, int64_t E,
+                           int Np) {
+    fe::GradFields P = {};
+    for (int x = 0; x < 3; ++x) P.j[x] = J + (int64_t)x * 3 * E;
+    for (int k = 0; k < nb; ++k) {
+        P.u[k] = u[k];
+        for (int x = 0; x < 3; ++x) P.out[k][x] = out[k] + (int64_t)x * E * Np;
+    }
+    return P;
+}
+
+// MFMA launch over the full tiles + generic kernels for the rest.  Jfull != nullptr: the planes
+// are those of a plain grad (one [3][3][E] array, [3][E][Np] outputs).
+int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const double* D, int nb, int nx,
+                       int64_t E, int Np, int opT, int variant, hipStream_t s) {
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
+    int64_t e_done = 0;
+    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+        int dbg = 0;
+#ifdef FE_EXPERIMENTS
+        if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
+#endif
+        int rc = FE_OK;
+        switch (Np) {   // wave tile = 16 M elements
+            case 35: rc = launch_grad<35, 1>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_grad<20, 2>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_grad<10, 3>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_grad<4, 5>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
+        }
+        if (rc != FE_OK) return rc;
+    }
+    if (e_done < E) {
+        const dim3 grid(generic_grid(E - e_done, Np)), block(256);
+        for (int k = 0; k < nb; ++k) {
+            if (Jfull) {
+                hipLaunchKernelGGL(fe::grad3d_generic_kernel, grid, block, 0, s, Jfull, D, P.u[k], P.out[k][0], E,
+                                   Np, e_done, opT);
+                continue;
+            }
+            for (int x = 0; x < 3; ++x)
+                if (P.out[k][x])
+                    hipLaunchKernelGGL(fe::divcomp3d_generic_kernel, grid, block, 0, s, P.j[x], D, P.u[k],
+                                       P.out[k][x], E, Np, e_done, opT, 0);
+        }
+    }
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
 // div then grad in one persistent launch (full tiles only; e_done_* report what was covered)
 template <int NP, int MG, int MD>
-int launch_graddiv(const double* J, const double* D, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd,
+int launch_graddiv(const double* J, const double* D, const fe::GradFields& Pg, const fe::FieldPtrs& Pd,
                    int64_t E, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
     using GG = fe::GradGeom<NP, MG>;
     using GD = fe::DivGeom<NP, MD>;
@@ -250,7 +308,7 @@ int launch_graddiv(const double* J, const double* D, const fe::FieldPtrs& Pg, co
 
 // div, grad and face-mass x nb (2..4) in one persistent launch (full tiles only)
 template <int NP, int NFP, int MG, int MD, int MF, int NB>
-int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd,
+int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe::FieldPtrs& Pd,
                      const fe::FieldPtrs& Pf, hipStream_t s) {
     using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
     static PerDeviceOnce once;
@@ -265,7 +323,7 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::FieldPtrs& Pg, const fe:
 }
 
 template <int NP, int NFP, int MG, int MD, int MF>
-int launch_waveop(fe::WaveOpArgs a, const fe::FieldPtrs& Pg, const fe::FieldPtrs& Pd, const fe::FieldPtrs& Pf,
+int launch_waveop(fe::WaveOpArgs a, const fe::GradFields& Pg, const fe::FieldPtrs& Pd, const fe::FieldPtrs& Pf,
                   int nb, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
     a.nTilesG = a.E / (16 * MG);
     a.nTilesD = a.E / (16 * MD);
@@ -359,12 +417,8 @@ int fe_grad3d_batched_f64(const double* J, const double* D, const double* const*
         return fe_grad3d_batched_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
                     variant, stream);
     }
-    fe::FieldPtrs P = {};
-    for (int k = 0; k < b; ++k) {
+    for (int k = 0; k < b; ++k)
         if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
-        P.v[k] = u[k];
-        P.out[k] = out[k];
-    }
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
@@ -374,31 +428,49 @@ int fe_grad3d_batched_f64(const double* J, const double* D, const double* const*
 #endif
         return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
     if (E == 0) return FE_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
-    int64_t e_done = 0;
-    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
-        int dbg = 0;
-#ifdef FE_EXPERIMENTS
-        if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
-#endif
-        int rc = FE_OK;
-        switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_grad<35, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_grad<20, 2>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_grad<10, 3>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_grad<4, 5>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-        }
-        if (rc != FE_OK) return rc;
+    return grad_fields_launch(grad_fields(J, u, out, b, E, Np), J, D, b, 3, E, Np, opT, variant,
+                              static_cast<hipStream_t>(stream));
+}
+
+int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* const* u,
+                        double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                        int32_t variant, void* stream) {
+    if (!J3 || !u || !out) return fail(FE_EINVAL, "grad planes: null pointer table");
+    if (b < 1) return fail(FE_EINVAL, "grad planes: b=%d, need at least one field", b);
+    if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
+        if (int rc = fe_gradplanes3d_f64(J3, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
+        return fe_gradplanes3d_f64(J3, D, u + FE_MAX_FIELDS, out + 3 * FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS,
+                                   op_flags, variant, stream);
     }
-    if (e_done < E)
-        for (int k = 0; k < b; ++k)
-            hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256),
-                               0, s, J, D, P.v[k], P.out[k], E, Np, e_done, opT);
-    FE_HIP_CHECK(hipGetLastError());
-    return FE_OK;
+    if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad planes: bad operator flags %d", op_flags);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "grad planes: unknown variant %d", variant);
+    fe::GradFields P = {};
+    int nx = -1;
+    for (int k = 0; k < b; ++k) {
+        int planes = 0;
+        for (int x = 0; x < 3; ++x) {
+            double* o = out[3 * k + x];
+            if (!o) continue;
+            if (int rc = check_common(J3[x], D, u[k], o, E, Np)) return rc;
+            P.out[k][x] = o;
+            ++planes;
+        }
+        if (planes == 0) return fail(FE_EINVAL, "grad planes: field %d has no output plane", k);
+        if (nx >= 0 && planes != nx)
+            return fail(FE_EINVAL, "grad planes: every field of a call needs the same number of planes (%d vs %d)",
+                        planes, nx);
+        nx = planes;
+        P.u[k] = u[k];
+    }
+    for (int x = 0; x < 3; ++x) {
+        if (!J3[x]) return fail(FE_EINVAL, "grad planes: null geometry-factor array %d", x);
+        if (reinterpret_cast<uintptr_t>(J3[x]) & 7u) return fail(FE_EINVAL, "device pointers must be 8-byte aligned");
+        P.j[x] = J3[x];
+    }
+    if (E == 0) return FE_OK;
+    return grad_fields_launch(P, nullptr, D, b, nx, E, Np, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, variant,
+                              static_cast<hipStream_t>(stream));
 }
 
 int fe_div3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
@@ -506,8 +578,8 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
     }
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    fe::FieldPtrs Pg = {}, Pd = {};
-    Pg.v[0] = u_grad; Pg.out[0] = grad_out;
+    const fe::GradFields Pg = grad_fields(J, &u_grad, &grad_out, 1, E, Np);
+    fe::FieldPtrs Pd = {};
     Pd.v[0] = v_div;  Pd.out[0] = div_out;
     int64_t done_g = 0, done_d = 0;
     int rc = FE_OK;
@@ -635,8 +707,8 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
     }
     if (bits & 7u) return fail(FE_EINVAL, "waveop: device pointers must be 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    fe::FieldPtrs Pg = {}, Pd = {}, Pf = {};
-    Pg.v[0] = u_grad; Pg.out[0] = grad_out;
+    const fe::GradFields Pg = grad_fields(J, &u_grad, &grad_out, 1, E, Np);
+    fe::FieldPtrs Pd = {}, Pf = {};
     Pd.v[0] = v_div;  Pd.out[0] = div_out;
     for (int k = 0; k < fe::kMaxFields; ++k) {
         Pf.v[k] = f[k < b ? k : 0];
@@ -729,6 +801,9 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
                 return fe_div3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
                                             a->variant, stream);
             return fe_div3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
+        case FE_FAMILY_GRADPLANES:
+            return fe_gradplanes3d_f64(a->j3, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
+                                       a->variant, stream);
         case FE_FAMILY_GRADDIV:
             return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
                                     a->variant, stream);

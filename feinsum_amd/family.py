@@ -28,7 +28,7 @@ import numpy as np
 
 from feinsum_amd.einsum import BatchedEinsum, SizeParam
 
-FAMILY_GRAD, FAMILY_DIV, FAMILY_GRADDIV, FAMILY_FACEMASS, FAMILY_DIVCOMP = 1, 2, 3, 4, 5
+FAMILY_GRAD, FAMILY_DIV, FAMILY_GRADDIV, FAMILY_FACEMASS, FAMILY_DIVCOMP, FAMILY_GRADPLANES = 1, 2, 3, 4, 5, 6
 FM_J_FE, FM_R_IFJ, FM_R_T = 1, 2, 4
 OP_TRANSPOSED, OP_J_ES = 1, 2
 

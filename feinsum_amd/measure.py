@@ -44,7 +44,8 @@ from feinsum_amd.contraction_schedule import ContractionSchedule, count_ops
 from feinsum_amd.diagnostics import (HipLibraryError, InvalidParameterError,
                                      NoDevicePeaksInfoError, TransformValidationError)
 from feinsum_amd.einsum import INT_CLASSES, BatchedEinsum, SizeParam
-from feinsum_amd.family import (FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_FACEMASS, FAMILY_GRAD, KernelPlan,
+from feinsum_amd.family import (FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_FACEMASS, FAMILY_GRAD,
+                                FAMILY_GRADPLANES, OP_J_ES, KernelPlan,
                                 match_family)
 
 logger = logging.getLogger(__name__)
@@ -225,6 +226,9 @@ class _FamilyLaunch:
         op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP) else "R"
         self.groups = []   # list of ArgPack (one per launch)
         in_role = "u" if op_role == "D" else "v"
+        self.group_family = plan.family
+        if plan.family == FAMILY_DIVCOMP and self._bind_planes(einsum, arg_dict, outs):
+            return
         # consecutive rows sharing J and the operator become one multi-field launch
         k = 0
         while k < len(rows):
@@ -248,10 +252,45 @@ class _FamilyLaunch:
             self.groups.append(pack)
             k = k2
 
+    def _bind_planes(self, einsum: BatchedEinsum, arg_dict: Mapping[str, Any], outs: Sequence[Any]) -> bool:
+        """Rows of 're,rij,ej->ei' that share u and D (e.g. the curl-type batch of
+        ``tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231``) go through the grad-type
+        planes launch, which forms D u once per field.  False: keep one launch per row."""
+        role, rows = self.plan.roles, einsum.args
+        if self.plan.layout_flags & OP_J_ES:
+            return False
+        if len({row[role["D"]].name for row in rows}) != 1:
+            return False
+        jnames = sorted({row[role["J"]].name for row in rows})
+        fields: dict = {}
+        for m, row in enumerate(rows):
+            fields.setdefault(row[role["u"]].name, {})[row[role["J"]].name] = m
+        n_planes = {len(planes) for planes in fields.values()}
+        if (len(jnames) > 3 or len(n_planes) != 1 or next(iter(n_planes)) < 2
+                or sum(len(planes) for planes in fields.values()) != len(rows)):
+            return False
+        jptrs = [arg_dict[jnames[min(x, len(jnames) - 1)]].data_ptr() for x in range(3)]
+        uptrs = [arg_dict[name].data_ptr() for name in fields]
+        optrs = [outs[planes[jn]].data_ptr() if jn in planes else None
+                 for planes in fields.values() for jn in (jnames + [None] * 3)[:3]]
+        pack = _hip.ArgPack()
+        ja, ua, oa = _hip._ptr_array(jptrs), _hip._ptr_array(uptrs), _hip._ptr_array(optrs)
+        self._keep += (ja, ua, oa)
+        pack.j3, pack.v, pack.outs = ja, ua, oa
+        pack.D = arg_dict[rows[0][role["D"]].name].data_ptr()
+        pack.E, pack.Np, pack.b = self.E, self.plan.params["Np"], len(uptrs)
+        pack.layout_flags, pack.variant = self.plan.layout_flags, self.variant
+        self.groups.append(pack)
+        self.group_family = FAMILY_GRADPLANES
+        return True
+
     def launch(self, stream_ptr: int) -> None:
         lib = _hip.load_library()
         for pack in self.groups:
-            if self.plan.family == FAMILY_GRAD:
+            if self.group_family == FAMILY_GRADPLANES:
+                _hip.check(lib.fe_gradplanes3d_f64(pack.j3, pack.D, pack.v, pack.outs, pack.E, pack.Np,
+                                                   pack.b, pack.layout_flags, pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_GRAD:
                 _hip.check(lib.fe_grad3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                      pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIV:
@@ -268,7 +307,7 @@ class _FamilyLaunch:
     def time_batch(self, n: int, stream_ptr: int) -> float:
         """Seconds for *n* launches of the whole batched einsum (HIP events)."""
         if len(self.groups) == 1:
-            return _hip.time_launches(self.plan.family, self.groups[0], n, stream_ptr) * 1e-3
+            return _hip.time_launches(self.group_family, self.groups[0], n, stream_ptr) * 1e-3
         import torch
 
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

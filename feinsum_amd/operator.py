@@ -104,7 +104,7 @@ class BoundOperator:
             if hasattr(b, "entry_point"):
                 names.append(b.entry_point)
             elif isinstance(b, _FamilyLaunch):
-                names += [f"fe_{b.plan.name}"] * len(b.groups)
+                names += ["fe_gradplanes" if b.group_family == 6 else f"fe_{b.plan.name}"] * len(b.groups)
             else:
                 names += ["fe_einsum_generic"] * len(b.launches)
         return tuple(names)

@@ -60,6 +60,7 @@ extern "C" {
 #define FE_FAMILY_GRADDIV  3
 #define FE_FAMILY_FACEMASS 4
 #define FE_FAMILY_DIVCOMP  5
+#define FE_FAMILY_GRADPLANES 6
 
 /* face-mass operand layouts (bit flags) */
 #define FE_FM_J_EF   0  /* J[E][nf]      (test_loopy_utils.py:41)            */
@@ -138,6 +139,21 @@ int fe_div3d_batched_f64(const double* J, const double* D,
                          int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                          int32_t variant, void* stream);
 
+/* grad-type batch over separate geometry-factor arrays and output planes:
+ *   out[3k + x][e,i] = sum_{r,j} J3[x][r,e] * D[r,i,j] * u[k][e,j],  k = 0..b-1, x = 0..2
+ * i.e. the rows of a batched 're,rij,ej->ei' / 're,rji,ej->ei' that share u[k] and D are
+ * evaluated together, D u[k] being formed once per field instead of once per row: the
+ * curl-type batch of 12 rows over six fields and three J arrays in
+ * tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231 is one call with b = 6.
+ *   J3:  HOST array of 3 device pointers, each [3][E]
+ *   u:   HOST array of b device pointers, each [E][Np]
+ *   out: HOST array of 3 b device pointers, each [E][Np] or NULL (plane not wanted); every
+ *        field needs the same number (1..3) of non-NULL planes. */
+int fe_gradplanes3d_f64(const double* const* J3, const double* D,
+                        const double* const* u, double* const* out,
+                        int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                        int32_t variant, void* stream);
+
 /* fused grad + div sharing J and D (BASELINE config 3), one persistent launch:
  *   grad_out[3][E][Np] from u_grad[E][Np];  div_out[E][Np] from v_div[3][E][Np] */
 int fe_graddiv3d_f64(const double* J, const double* D,
@@ -189,6 +205,7 @@ typedef struct fe_argpack {
     double* const* outs;      /* ... and outputs (host arrays of b ptrs)        */
     int64_t E;
     int32_t Np, nf, Nfp, b, layout_flags, variant;   /* layout_flags: FE_FM_* or FE_OP_* by family */
+    const double* const* j3;  /* FE_FAMILY_GRADPLANES: 3 ptrs; v = u (b), outs = planes (3 b) */
 } fe_argpack;
 
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed

@@ -90,3 +90,16 @@ def batched_div(b=3, Np=NP, op="rij"):
         f"xre,{op},xej->ei",
         [[f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)), f.array(f"u{i}", (3, "E", Np))]
          for i in range(b)])
+
+
+CROSS_FIELDS = {"ux": ("Jy", "Jz"), "uy": ("Jx", "Jz"), "uz": ("Jx", "Jy"),
+                "vx": ("Jy", "Jz"), "vy": ("Jx", "Jz"), "vz": ("Jx", "Jy")}
+
+
+def cross_product_batch(Np=NP, op="rji", fields=CROSS_FIELDS):
+    # the curl-type batch of tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231:
+    # every field component is differentiated along the two other directions
+    return f.batched_einsum(
+        f"re,{op},ej->ei",
+        [[f.array(J, (3, "E")), f.array("D", (3, Np, Np)), f.array(u, ("E", Np))]
+         for u, js in fields.items() for J in js])

@@ -188,6 +188,44 @@ def test_batched_grad_matches_single_field_launches_bitwise(torch_cuda):
         assert np.array_equal(got[name], next(iter(one.values())))
 
 
+@pytest.mark.parametrize("Np", [4, 10, 20, 35, 56])
+@pytest.mark.parametrize("E", [15, 16, 97, 1003])
+def test_cross_product_batch_shares_the_operator_product(torch_cuda, Np, E):
+    # 're,rji,ej->ei' x 12 over six fields and three J arrays
+    # (tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231): rows sharing u and D are one
+    # grad-type launch with two output planes per field
+    from feinsum_amd.measure import _bind
+
+    for op in ("rji", "rij"):
+        expr = dg.cross_product_batch(Np, op)
+        host = generate_host_input_arrays(expr, E, np_seed=Np + E)
+        ref = _oracle(expr, host)
+        for v in ["auto", "generic"] + (["mfma"] if Np != 56 else []):
+            _assert_close(_run(torch_cuda, expr, host, transform=v), ref)
+    dev = {k: torch_cuda.from_numpy(v).cuda() for k, v in host.items()}
+    _, bound, _ = _bind(expr, 0, dev, None, None)
+    assert bound.group_family == 6 and len(bound.groups) == 1 and bound.groups[0].b == 6
+
+
+def test_div_component_rows_that_cannot_share_stay_separate(torch_cuda):
+    from feinsum_amd.measure import _bind
+
+    E, Np = 1003, 35
+    cases = {
+        "three planes": {"u": ("Jx", "Jy", "Jz"), "w": ("Jx", "Jy", "Jz")},        # a grad, row by row
+        "uneven": {"u": ("Jx", "Jy"), "w": ("Jz",)},
+        "one each": {"ux": ("Jx",), "uy": ("Jy",), "uz": ("Jz",)},
+        "four J arrays": {"u": ("Ja", "Jb"), "w": ("Jc", "Jd")},
+    }
+    for name, fields in cases.items():
+        expr = dg.cross_product_batch(Np, "rij", fields)
+        host = generate_host_input_arrays(expr, E, np_seed=3)
+        _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+        dev = {k: torch_cuda.from_numpy(v).cuda() for k, v in host.items()}
+        _, bound, _ = _bind(expr, 0, dev, None, None)
+        assert (bound.group_family == 6) == (name == "three planes"), name
+
+
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
 def test_face_mass_field_counts(torch_cuda, b):
     # b = 1 (generic only), odd counts, > 8 fields (several launches), 19 as in the archive
