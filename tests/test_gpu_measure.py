@@ -182,6 +182,19 @@ def test_wave_operator_single_launch(Np, Nfp, E):
     assert op.time_batch(2) > 0
 
 
+def test_record_facts_measures_and_retrieve_picks_the_faster_variant(tmp_path):
+    # the archive loop of examples/howto_autotune.py: record -> query -> retrieve -> timeit
+    db = str(tmp_path / "facts.sqlite")
+    expr = dg.grad()
+    for v in ("generic", "mfma"):
+        f.record_facts(expr, 0, v, database=db, long_dim_length=20_000)
+    facts = {q.transform_id: q for q in f.query(expr, f.DeviceQueue(0).device, database=db)}
+    assert facts["mfma"].runtime_in_sec < facts["generic"].runtime_in_sec
+    best = f.retrieve(expr, f.DeviceQueue(0).device, database=db)
+    assert dict(best) == {"variant": "mfma"}
+    assert f.timeit(expr, cq=0, transform=best, long_dim_length=20_000) > 0
+
+
 def test_launchers_are_graph_capturable():
     """No allocation / synchronisation inside the launch path: the three family launchers can be
     captured into a HIP graph on a side stream and replayed (inputs updated in place)."""

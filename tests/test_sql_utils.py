@@ -1,0 +1,93 @@
+"""Canonical keys and the timing-fact archive (reference: src/feinsum/sql_utils.py,
+src/feinsum/canonicalization.py:1087; archive round trips as in examples/howto_autotune.py)."""
+
+import sqlite3
+
+import numpy as np
+import pytest
+
+import feinsum_amd as f
+from feinsum_amd import sql_utils
+from feinsum_amd.canonicalization import canonicalize_einsum
+
+import dg
+
+
+def test_canonical_form_ignores_names_and_operand_order():
+    ref = canonicalize_einsum(dg.grad())
+    same = f.einsum("ej,xre,rij->xei", f.array("w", ("N", 35)), f.array("G", (3, 3, "N")),
+                    f.array("Q", (3, 35, 35)))
+    renamed = f.einsum("abc,bde,ce->acd", f.array("J", (3, 3, "K")), f.array("R", (3, 35, 35)),
+                       f.array("u", ("K", 35)))
+    assert canonicalize_einsum(same) == ref == canonicalize_einsum(renamed)
+    assert canonicalize_einsum(ref) == ref                                   # idempotent
+    assert [a.name for a in ref.args[0]] == ["arg_0", "arg_1", "arg_2"]
+    # different sizes, layouts or field counts are different keys
+    others = [dg.grad(20), dg.grad_t(), dg.div(), dg.face_mass(4), dg.face_mass(3), dg.face_mass_ifj_fe(4),
+              dg.batched_grad(2), dg.batched_div_components()]
+    keys = {sql_utils._key(canonicalize_einsum(e)) for e in others + [dg.grad()]}
+    assert len(keys) == len(others) + 1
+    # arrays shared between rows stay shared
+    fm = canonicalize_einsum(dg.face_mass(4))
+    assert sorted(len({row[k].name for row in fm.args}) for k in range(3)) == [1, 1, 4]
+
+
+def test_record_query_retrieve_round_trip(tmp_path):
+    db = str(tmp_path / "facts.sqlite")
+    dev = f.FakeCLDevice("AMD Instinct MI355X")
+    grad = dg.grad()
+    with pytest.raises(RuntimeError, match="timing facts table"):
+        sql_utils.query(grad, dev, database=db)
+    sql_utils.record_facts(grad, None, "generic", database=db, runtime_in_sec=4.0e-3, device_name=dev.name)
+    sql_utils.record_facts(grad, None, "mfma", database=db, runtime_in_sec=2.0e-5, device_name=dev.name)
+    sql_utils.record_facts(dg.div(), None, "mfma", database=db, runtime_in_sec=2.1e-5, device_name=dev.name)
+
+    facts = sql_utils.query(grad, dev, database=db)
+    assert sorted(q.transform_id for q in facts) == ["generic", "mfma"]
+    best = max(facts, key=lambda q: q.giga_op_rate(np.float64))
+    assert best.transform_id == "mfma"
+    assert best.giga_op_info[np.dtype("float64")] == pytest.approx(0.798)          # archive pin: 0.798 GFLOP @1e5
+    assert best.giga_op_rate("float64") == pytest.approx(0.798 / 2.0e-5)
+    assert dict(sql_utils.retrieve(grad, dev, database=db)) == {"variant": "mfma"}
+    only_generic = sql_utils.retrieve(grad, dev, database=db, consider_query=lambda q: q.transform_id == "generic")
+    assert dict(only_generic) == {"variant": "generic"}
+    # same einsum spelled differently finds the same facts; another device or einsum finds none
+    spelled = f.einsum("ej,xre,rij->xei", f.array("w", ("N", 35)), f.array("G", (3, 3, "N")),
+                       f.array("Q", (3, 35, 35)))
+    assert len(sql_utils.query(spelled, dev, database=db)) == 2
+    assert sql_utils.query(grad, f.FakeCLDevice("NVIDIA TITAN V"), database=db) == ()
+    with pytest.raises(f.NoFactInDatabaseError):
+        sql_utils.query(dg.face_mass(), dev, database=db, err_if_no_results=True)
+    with pytest.raises(f.NoFactInDatabaseError):
+        sql_utils.retrieve(grad, dev, database=db, consider_query=lambda q: False)
+    with pytest.raises(ValueError):
+        sql_utils.record_facts(grad, None, "no-such-variant", database=db, runtime_in_sec=1.0, device_name="x")
+
+    timed = sql_utils.get_timed_einsums_in_db(dev, database=db)
+    assert set(timed) == {canonicalize_einsum(grad), canonicalize_einsum(dg.div())}
+
+
+def test_table_has_the_reference_columns(tmp_path):
+    # src/feinsum/sql_utils.py:389-410
+    conn = sqlite3.connect(str(tmp_path / "facts.sqlite"))
+    sql_utils.record_facts(dg.face_mass(), None, "mfma", database=conn, runtime_in_sec=1e-4,
+                           device_name="AMD Instinct MI355X")
+    cols = [r[1] for r in conn.execute(f"PRAGMA table_info({sql_utils.TIMINGS_TABLENAME})")]
+    assert cols == ["ID", "subscripts", "index_to_length", "args", "arg_to_dtype", "device_name", "transform_id",
+                    "transform_params", "runtime_in_sec", "compiler_version", "giga_op_info", "timestamp"]
+    row = conn.execute(f"SELECT device_name, transform_params, giga_op_info, args FROM {sql_utils.TIMINGS_TABLENAME}").fetchone()
+    assert row[0] == "AMD_Instinct_MI355X" and row[1] == "{}"
+    import json
+
+    assert json.loads(row[2]) == {"float64": pytest.approx(1.704)}                      # archive pin for face-mass b=4
+    assert row[3].count("arg_0") == 4
+
+
+def test_shipped_archive_has_the_headline_facts():
+    import os
+
+    if not os.path.exists(sql_utils.DEFAULT_DB):
+        pytest.skip("no shipped archive yet")
+    dev = f.FakeCLDevice("AMD Instinct MI355X")
+    for expr in (dg.grad(), dg.div(), dg.face_mass()):
+        assert dict(sql_utils.retrieve(expr, dev))["variant"] == "mfma"
