@@ -25,7 +25,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MF
 EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
     "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
-    "fe_grad3d_batched_f64", "fe_div3d_batched_f64", "fe_gradplanes3d_f64",
+    "fe_grad3d_batched_f64", "fe_div3d_batched_f64", "fe_gradplanes3d_f64", "fe_matapply_f64",
     "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
@@ -112,6 +112,9 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_matapply_f64.restype = C.c_int
+    lib.fe_matapply_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_gradplanes3d_f64.restype = C.c_int
     lib.fe_gradplanes3d_f64.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
@@ -219,6 +222,15 @@ def gradplanes3d(J3: Sequence[int], D: int, u: Sequence[int], out: Sequence[Opti
         raise InvalidParameterError("grad planes: need 3 J arrays and 3 output slots per field")
     check(load_library().fe_gradplanes3d_f64(_ptr_array(J3), D, _ptr_array(u), _ptr_array(out), E, Np,
                                              len(u), op_flags, variant_code(variant), stream))
+
+
+def matapply(J: Optional[int], D: int, u: Sequence[int], out: Sequence[int], E: int, Np: int,
+             variant=None, stream: int = 0, op_flags: int = 0) -> None:
+    """``out_k[e,i] = J[e] sum_j D[i,j] u_k[e,j]`` for ``len(u)`` fields (``J = None``: no factor)."""
+    if len(u) != len(out):
+        raise InvalidParameterError("matapply: need as many outputs as fields")
+    check(load_library().fe_matapply_f64(J, D, _ptr_array(u), _ptr_array(out), E, Np, len(u), op_flags,
+                                         variant_code(variant), stream))
 
 
 def graddiv3d(J: int, D: int, u_grad: int, v_div: int, grad_out: int, div_out: int, E: int,

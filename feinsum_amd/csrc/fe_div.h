@@ -24,6 +24,9 @@
 // of test/test_codegen.py:34-66 and tuning/impls/re_rij_ej_to_ei.py) shares everything but the
 // B fragment, which is the single multiply J[s,e] * u[e,j] from ONE u plane and three J rows
 // (J stored [3][E], or [E][3] as in examples/dg_wave_div.py 'es,sij,ej->ei').
+// MODE 2 ('e,ij,ej->ei': out[e,i] = J[e] sum_j D[i,j] u[e,j], tuning/impls/
+// e_ij_ej_to_ei_no_prftch.py:30-38) and MODE 3 ('ij,ej->ei', tuning/impls/ij_ej_to_ei_no_prftch.py)
+// are the same with ONE operator component (NC = 1): B fragment = J[e] u[e,j], or u[e,j] itself.
 // Data movement as in fe_grad.h; a wave tile is 16 M elements.  The three u planes of a tile
 // leave no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a tile are
 // computed up front, which frees the u buffer, and the next tile's loads are issued before
@@ -37,8 +40,9 @@ template <int NP, int M, int MODE = 0>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int NPLANES = MODE ? 1 : 3;        // u planes per tile
-    static constexpr int NJ = MODE ? 3 : 9;             // J values per element
-    static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = 3 KSJ, ordered (jq, r)
+    static constexpr int NC = MODE >= 2 ? 1 : 3;        // operator components r
+    static constexpr int NJ = MODE == 0 ? 9 : MODE == 1 ? 3 : MODE == 2 ? 1 : 0;   // J values per element
+    static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = NC KSJ, ordered (jq, r)
     static constexpr int BT = NP / 16;                  // 16-row tiles
     static constexpr int NR = NP - 16 * BT;             // rows left for the 4x4x4 groups
     static constexpr int NS = (NR + 3) / 4;             // 4-row groups
@@ -51,11 +55,11 @@ struct DivGeom {
     struct WaveLds {
         double u[NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
         double o[SUB_D];              // output transposition buffer (one 16-element sub-tile)
-        double j[NJ * TEL];           // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s])
+        double j[NJ > 0 ? NJ * TEL : 2];   // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s]; MODE 2: J[..])
     };
     static constexpr int WAVES = 4;
-    static constexpr int ASMALL_D = 3 * KSJ * NS * 16;  // [k-step][group][g][row] doubles, per block
-    static constexpr int OP_D = 3 * NP * NP;
+    static constexpr int ASMALL_D = NC * KSJ * NS * 16; // [k-step][group][g][row] doubles, per block
+    static constexpr int OP_D = NC * NP * NP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
     static constexpr int LDS_BYTES = (WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8) + ASMALL_D * 8;
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
@@ -78,7 +82,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     // ---- A fragments from the LDS-staged operator.  16x16x4: lane (g, n) supplies
     //      A[row 16t + n][k = g];  4x4x4_4b group q: lane (g, n) supplies block n/4, row
     //      16 BT + 4q + n%4, k = g -- identical for the four blocks, kept once in LDS.
-    double abig[G::BT > 0 ? G::BT : 1][G::KSJ][3];
+    constexpr int NC = G::NC;
+    double abig[G::BT > 0 ? G::BT : 1][G::KSJ][NC];
     double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - G::ASMALL_D * 8));
     {
         double* dl = reinterpret_cast<double*>(smem);
@@ -88,7 +93,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         for (int jq = 0; jq < G::KSJ; ++jq) {
             const int j = 4 * jq + g;
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < NC; ++r)
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t)
                     abig[t][jq][r] = (j < NP) ? dl[opT ? (r * NP + j) * NP + 16 * t + n   // opT: D stored [r][j][i]
@@ -96,7 +101,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         }
         for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
             const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
-            const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / 3) + gg, r = ks % 3;
+            const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
             asmall[idx] = (j < NP && i < NP) ? dl[opT ? (r * NP + j) * NP + i : (r * NP + i) * NP + j] : 0.0;
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
@@ -127,7 +132,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             const int q = c * 64 + lane;
             const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
             // rows of E doubles; MODE 1 with J stored [E][3]: one contiguous span of 3 TEL doubles
-            const char* src = (MODE && jes) ? jb + e0 * 16 + q * 16 : jb + ((int64_t)row * E) * 8 + col * 16;
+            const char* src = (MODE == 1 && jes) ? jb + e0 * 16 + q * 16 : jb + ((int64_t)row * E) * 8 + col * 16;
             if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     };
@@ -149,13 +154,14 @@ __device__ __forceinline__ void div3d_mfma_body(
         first = false;
 
         // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
-        double bfrag[M][G::KSJ][3];
+        double bfrag[M][G::KSJ][NC];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            double jac[G::NJ];
+            double jac[G::NJ > 0 ? G::NJ : 1];
 #pragma unroll
-            for (int k = 0; k < G::NJ; ++k)   // jac[x*3 + r]  (MODE 1: jac[s])
-                jac[k] = (MODE && jes) ? L->j[(16 * m + n) * 3 + k] : L->j[k * G::TEL + 16 * m + n];
+            for (int k = 0; k < G::NJ; ++k)   // jac[x*3 + r]  (MODE 1: jac[s]; MODE 2: jac[0] = J[e])
+                jac[k] = (MODE == 1 && jes) ? L->j[(16 * m + n) * 3 + k] : L->j[k * G::TEL + 16 * m + n];
+            if (G::NJ == 0) jac[0] = 1.0;
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
                 const int j = 4 * jq + g;
@@ -165,10 +171,11 @@ __device__ __forceinline__ void div3d_mfma_body(
                 double u2 = L->u[MODE ? 0 : 2][(16 * m + n) * NP + jc];
                 if (j >= NP) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    bfrag[m][jq][r] = MODE ? jac[r] * u0
-                                           : jac[0 * 3 + r] * u0 + jac[(MODE ? 0 : 1) * 3 + r] * u1 +
-                                                 jac[(MODE ? 0 : 2) * 3 + r] * u2;
+                for (int r = 0; r < NC; ++r)
+                    bfrag[m][jq][r] = MODE == 3 ? u0
+                                    : MODE      ? jac[r] * u0
+                                                : jac[0 * 3 + r] * u0 + jac[(MODE ? 0 : 1) * 3 + r] * u1 +
+                                                      jac[(MODE ? 0 : 2) * 3 + r] * u2;
             }
         }
         // the u / J tiles are now in registers: hand the buffers back to the DMA engine
@@ -177,7 +184,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
+                for (int r = 0; r < NC; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
 
 #pragma unroll
@@ -194,7 +201,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) sum += bfrag[m][jq][r];
+                    for (int r = 0; r < NC; ++r) sum += bfrag[m][jq][r];
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t) acc[t] = v4d{sum, sum, sum, abig[t][0][0]};
 #pragma unroll
@@ -203,13 +210,13 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
+                    for (int r = 0; r < NC; ++r) {
 #pragma unroll
                         for (int t = 0; t < G::BT; ++t)
                             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[m][jq][r], acc[t], 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < G::NS; ++q)
-                            accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16],
+                            accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16],
                                                                          bfrag[m][jq][r], accs[q], 0, 0, 0);
                     }
             }

@@ -59,6 +59,22 @@ __global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
     out[e * Np + i] = acc;
 }
 
+// element-local operator: out[e,i] = (J ? J[e] : 1) * sum_j D[i,j] u[e,j]   ('e,ij,ej->ei', 'ij,ej->ei')
+__global__ __launch_bounds__(256) void matapply_generic_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (E - e_begin) * Np) return;
+    const int64_t e = e_begin + idx / Np;
+    const int i = (int)(idx % Np);
+    const double* d = D + (opT ? i : (int64_t)i * Np);
+    const int sj = opT ? Np : 1;
+    const double* ue = u + e * Np;
+    double acc = 0.0;
+    for (int j = 0; j < Np; ++j) acc += d[j * sj] * ue[j];
+    out[e * Np + i] = J ? J[e] * acc : acc;
+}
+
 // face-mass: out_k[e,i] = sum_{f,j} J[e,f] R[f,i,j] v_k[f,e,j]
 //   jEs / jFs : strides of J along e and f;  rF / rI / rJ : strides of R along f, i and j
 template <int NB>

@@ -198,6 +198,29 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     return FE_OK;
 }
 
+// 'e,ij,ej->ei' (MODE 2) / 'ij,ej->ei' (MODE 3): the one-component instances of the div template
+template <int NP, int M, int MODE>
+int launch_matapply_mode(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
+                         hipStream_t s, int64_t* e_done) {
+    using G = fe::DivGeom<NP, M, MODE>;
+    const int64_t nTiles = E / G::TEL;
+    *e_done = nTiles * G::TEL;
+    if (nTiles == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, MODE>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
+                       G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+    return FE_OK;
+}
+
+template <int NP, int M>
+int launch_matapply(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
+                    hipStream_t s, int64_t* e_done) {
+    return J ? launch_matapply_mode<NP, M, 2>(J, D, P, nb, E, opT, s, e_done)
+             : launch_matapply_mode<NP, M, 3>(J, D, P, nb, E, opT, s, e_done);
+}
+
 template <int NP, int NFP, int M, int NB>
 int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
@@ -563,6 +586,52 @@ int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* 
     return FE_OK;
 }
 
+int fe_matapply_f64(const double* J, const double* D, const double* const* u, double* const* out, int64_t E,
+                    int32_t Np, int32_t b, int32_t op_flags, int32_t variant, void* stream) {
+    if (!u || !out) return fail(FE_EINVAL, "matapply: null pointer table");
+    if (b < 1) return fail(FE_EINVAL, "matapply: b=%d, need at least one field", b);
+    if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
+        if (int rc = fe_matapply_f64(J, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
+        return fe_matapply_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
+                               variant, stream);
+    }
+    fe::FieldPtrs P = {};
+    for (int k = 0; k < b; ++k) {
+        if (int rc = check_common(J ? J : D, D, u[k], out[k], E, Np)) return rc;   // J is optional
+        P.v[k] = u[k];
+        P.out[k] = out[k];
+    }
+    if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "matapply: bad operator flags %d", op_flags);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+        return fail(FE_EUNSUPPORTED, "matapply: unknown variant %d", variant);
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 15 || Np == 10 || Np == 6 || Np == 4 || Np == 3;
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "matapply: MFMA variant is compiled for Np in {3, 4, 6, 10, 15, 20, 35} (Np=%d)", Np);
+    int64_t e_done = 0;
+    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+        int rc = FE_OK;
+        switch (Np) {   // wave tile = 16 M elements: a few KB per tile at every order
+            case 35: rc = launch_matapply<35, 2>(J, D, P, b, E, opT, s, &e_done); break;
+            case 20: rc = launch_matapply<20, 4>(J, D, P, b, E, opT, s, &e_done); break;
+            case 15: rc = launch_matapply<15, 4>(J, D, P, b, E, opT, s, &e_done); break;
+            case 10: rc = launch_matapply<10, 6>(J, D, P, b, E, opT, s, &e_done); break;
+            case 6: rc = launch_matapply<6, 8>(J, D, P, b, E, opT, s, &e_done); break;
+            case 4: rc = launch_matapply<4, 8>(J, D, P, b, E, opT, s, &e_done); break;
+            default: rc = launch_matapply<3, 8>(J, D, P, b, E, opT, s, &e_done); break;
+        }
+        if (rc != FE_OK) return rc;
+    }
+    if (e_done < E)
+        for (int k = 0; k < b; ++k)
+            hipLaunchKernelGGL(fe::matapply_generic_kernel, dim3(generic_grid(E - e_done, Np)), dim3(256), 0, s,
+                               J, D, P.v[k], P.out[k], E, Np, e_done, opT);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
 int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, const double* v_div,
                      double* grad_out, double* div_out, int64_t E, int32_t Np, int32_t variant,
                      void* stream) {
@@ -804,6 +873,9 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
         case FE_FAMILY_GRADPLANES:
             return fe_gradplanes3d_f64(a->j3, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
                                        a->variant, stream);
+        case FE_FAMILY_MATAPPLY:
+            return fe_matapply_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags, a->variant,
+                                   stream);
         case FE_FAMILY_GRADDIV:
             return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
                                     a->variant, stream);

@@ -45,7 +45,7 @@ from feinsum_amd.diagnostics import (HipLibraryError, InvalidParameterError,
                                      NoDevicePeaksInfoError, TransformValidationError)
 from feinsum_amd.einsum import INT_CLASSES, BatchedEinsum, SizeParam
 from feinsum_amd.family import (FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_FACEMASS, FAMILY_GRAD,
-                                FAMILY_GRADPLANES, OP_J_ES, KernelPlan,
+                                FAMILY_GRADPLANES, FAMILY_MATAPPLY, OP_J_ES, KernelPlan,
                                 match_family)
 
 logger = logging.getLogger(__name__)
@@ -219,11 +219,12 @@ class _FamilyLaunch:
         role = plan.roles
         rows = einsum.args
         first = rows[0]
-        long_axis = einsum.in_idx_sets[role["J"]].index(plan.long_index)
-        self.E = int(arg_dict[first[role["J"]].name].shape[long_axis])
+        long_role = "J" if "J" in role else "u"       # 'ij,ej->ei' has no geometry factor
+        long_axis = einsum.in_idx_sets[role[long_role]].index(plan.long_index)
+        self.E = int(arg_dict[first[role[long_role]].name].shape[long_axis])
         self._keep = (arg_dict, outs)
         p = plan.params
-        op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP) else "R"
+        op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_MATAPPLY) else "R"
         self.groups = []   # list of ArgPack (one per launch)
         in_role = "u" if op_role == "D" else "v"
         self.group_family = plan.family
@@ -232,15 +233,16 @@ class _FamilyLaunch:
         # consecutive rows sharing J and the operator become one multi-field launch
         k = 0
         while k < len(rows):
-            jn, rn = rows[k][role["J"]].name, rows[k][role[op_role]].name
+            jname = lambda row: row[role["J"]].name if "J" in role else None   # noqa: E731
+            jn, rn = jname(rows[k]), rows[k][role[op_role]].name
             k2 = k + 1
             while (plan.family != FAMILY_DIVCOMP and k2 < len(rows)
-                   and rows[k2][role["J"]].name == jn and rows[k2][role[op_role]].name == rn):
+                   and jname(rows[k2]) == jn and rows[k2][role[op_role]].name == rn):
                 k2 += 1
             vptrs = [arg_dict[rows[m][role[in_role]].name].data_ptr() for m in range(k, k2)]
             optrs = [outs[m].data_ptr() for m in range(k, k2)]
             pack = _hip.ArgPack()
-            pack.J = arg_dict[jn].data_ptr()
+            pack.J = arg_dict[jn].data_ptr() if jn is not None else None
             pack.D = arg_dict[rn].data_ptr()
             pack.u, pack.out = vptrs[0], optrs[0]
             va, oa = _hip._ptr_array(vptrs), _hip._ptr_array(optrs)
@@ -296,6 +298,9 @@ class _FamilyLaunch:
             elif self.plan.family == FAMILY_DIV:
                 _hip.check(lib.fe_div3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                     pack.b, pack.layout_flags, pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_MATAPPLY:
+                _hip.check(lib.fe_matapply_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np, pack.b,
+                                               pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIVCOMP:
                 _hip.check(lib.fe_divcomp3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
                                                 pack.layout_flags, pack.variant, stream_ptr))

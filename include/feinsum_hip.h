@@ -61,6 +61,7 @@ extern "C" {
 #define FE_FAMILY_FACEMASS 4
 #define FE_FAMILY_DIVCOMP  5
 #define FE_FAMILY_GRADPLANES 6
+#define FE_FAMILY_MATAPPLY 7
 
 /* face-mass operand layouts (bit flags) */
 #define FE_FM_J_EF   0  /* J[E][nf]      (test_loopy_utils.py:41)            */
@@ -153,6 +154,17 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D,
                         const double* const* u, double* const* out,
                         int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                         int32_t variant, void* stream);
+
+/* element-local operator, b fields sharing J and D:
+ *   out_k[e,i] = J[e] * sum_j D[i,j] * u_k[e,j]      'e,ij,ej->ei' x b
+ *                                                    (tuning/impls/e_ij_ej_to_ei_no_prftch.py:30-38)
+ *   J == NULL:   out_k[e,i] = sum_j D[i,j] u_k[e,j]  'ij,ej->ei' (tuning/impls/ij_ej_to_ei_no_prftch.py)
+ *   J [E] or NULL   D [Np][Np] ([Np(j)][Np(i)] with FE_OP_TRANSPOSED)   u_k, out_k [E][Np]
+ *   u, out: HOST arrays of b device pointers.  MFMA kernels for Np in {3,4,6,10,15,20,35}. */
+int fe_matapply_f64(const double* J, const double* D,
+                    const double* const* u, double* const* out,
+                    int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                    int32_t variant, void* stream);
 
 /* fused grad + div sharing J and D (BASELINE config 3), one persistent launch:
  *   grad_out[3][E][Np] from u_grad[E][Np];  div_out[E][Np] from v_div[3][E][Np] */

@@ -103,3 +103,15 @@ def cross_product_batch(Np=NP, op="rji", fields=CROSS_FIELDS):
         f"re,{op},ej->ei",
         [[f.array(J, (3, "E")), f.array("D", (3, Np, Np)), f.array(u, ("E", Np))]
          for u, js in fields.items() for J in js])
+
+
+def mass_apply(b=4, Np=NP, op="ij"):
+    # per-element factor times a dense operator: tuning/impls/e_ij_ej_to_ei_no_prftch.py:30-38
+    return f.batched_einsum(
+        f"e,{op},ej->ei",
+        [[f.array("J", ("E",)), f.array("D", (Np, Np)), f.array(f"u{i}", ("E", Np))] for i in range(b)])
+
+
+def operator_apply(Np=NP, op="ij"):
+    # tuning/impls/ij_ej_to_ei_no_prftch.py
+    return f.einsum(f"{op},ej->ei", f.array("D", (Np, Np)), f.array("u", ("E", Np)))

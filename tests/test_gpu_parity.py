@@ -226,6 +226,25 @@ def test_div_component_rows_that_cannot_share_stay_separate(torch_cuda):
         assert (bound.group_family == 6) == (name == "three planes"), name
 
 
+@pytest.mark.parametrize("Np", [3, 4, 6, 10, 15, 20, 35, 56])
+@pytest.mark.parametrize("E", [15, 16, 127, 128, 129, 1003, 10007])
+def test_element_local_operator(torch_cuda, Np, E):
+    # 'e,ij,ej->ei' x b (b = 4, 5, 6, 16 in the archive) and 'ij,ej->ei', plain and transposed operator:
+    # the one-component instances of the div template; wave tiles of 32 .. 128 elements
+    variants = ["auto", "generic"] + (["mfma"] if Np != 56 else [])
+    for expr in (dg.mass_apply(4, Np), dg.mass_apply(5, Np, "ji"), dg.operator_apply(Np), dg.operator_apply(Np, "ji")):
+        host = generate_host_input_arrays(expr, E, np_seed=Np + E)
+        ref = _oracle(expr, host)
+        for v in variants:
+            _assert_close(_run(torch_cuda, expr, host, transform=v), ref)
+
+
+def test_element_local_operator_many_fields(torch_cuda):
+    expr = dg.mass_apply(16, 20)
+    host = generate_host_input_arrays(expr, 4099, np_seed=16)
+    _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+
+
 @pytest.mark.parametrize("b", [1, 2, 3, 5, 8, 9, 19])
 def test_face_mass_field_counts(torch_cuda, b):
     # b = 1 (generic only), odd counts, > 8 fields (several launches), 19 as in the archive
