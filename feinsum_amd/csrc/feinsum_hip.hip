@@ -834,13 +834,52 @@ int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void
         P.p[p] = operands[p];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
-    if (d->dtype == FE_DTYPE_F64)
-        hipLaunchKernelGGL(fe::einsum_generic_kernel<double>, grid, block, 0, s, *d, P,
-                           static_cast<double*>(out), n_out, n_sum);
-    else
-        hipLaunchKernelGGL(fe::einsum_generic_kernel<float>, grid, block, 0, s, *d, P,
-                           static_cast<float*>(out), n_out, n_sum);
+    const dim3 block(256);
+    const bool f64 = d->dtype == FE_DTYPE_F64;
+
+    // pointwise product of congruent contiguous operands: a vectorised stream
+    bool pointwise = d->n_sum == 0;
+    for (int p = 0; p < d->n_operands && pointwise; ++p) {
+        int64_t dense = 1;
+        for (int k = d->n_out - 1; k >= 0; --k) {
+            if (d->out_extent[k] != 1 && d->op_out_stride[p][k] != dense) pointwise = false;
+            dense *= d->out_extent[k];
+        }
+    }
+    if (pointwise) {
+        const int64_t want = (n_out / 2 + 255) / 256 + 1, cap = 32 * (int64_t)device_cu_count();
+        const dim3 grid((unsigned)(want < cap ? want : cap));
+        if (f64)
+            hipLaunchKernelGGL(fe::einsum_pointwise_kernel<double>, grid, block, 0, s, P, d->n_operands,
+                               static_cast<double*>(out), n_out);
+        else
+            hipLaunchKernelGGL(fe::einsum_pointwise_kernel<float>, grid, block, 0, s, P, d->n_operands,
+                               static_cast<float*>(out), n_out);
+        FE_HIP_CHECK(hipGetLastError());
+        return FE_OK;
+    }
+
+    // lanes per output entry: > 1 when the fastest summation index is contiguous in an operand
+    int group = 1;
+    if (d->n_sum > 0 && n_sum >= 8) {
+        bool contiguous = false;
+        for (int p = 0; p < d->n_operands; ++p) contiguous |= d->op_sum_stride[p][d->n_sum - 1] == 1;
+        if (contiguous) group = n_sum >= 32 ? 16 : 4;
+    }
+    if (n_out * group >= ((int64_t)1 << 39)) group = 1;
+    const dim3 grid((unsigned)((n_out * group + 255) / 256));
+#define FE_EINSUM_CASE(T, G) \
+    hipLaunchKernelGGL((fe::einsum_generic_kernel<T, G>), grid, block, 0, s, *d, P, static_cast<T*>(out), n_out, n_sum)
+    if (f64) {
+        if (group == 16) FE_EINSUM_CASE(double, 16);
+        else if (group == 4) FE_EINSUM_CASE(double, 4);
+        else FE_EINSUM_CASE(double, 1);
+    } else {
+        if (group == 16) FE_EINSUM_CASE(float, 16);
+        else if (group == 4) FE_EINSUM_CASE(float, 4);
+        else FE_EINSUM_CASE(float, 1);
+    }
+#undef FE_EINSUM_CASE
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }

@@ -282,6 +282,39 @@ def test_generic_einsum_kernel(torch_cuda):
     _assert_close(_run(torch_cuda, g, host), _oracle(g, host))
 
 
+@pytest.mark.parametrize("E", [1, 7, 64, 1003, 100003])
+def test_generic_einsum_reductions_and_pointwise(torch_cuda, E):
+    # the remaining families of the reference's archive (tuning/impls/ij_j_to_i.py, ij_to_i.py,
+    # ij_ij_to_ij.py, ijk_ijk_to_ijk.py): lane groups per output for contiguous summation
+    # indices, a vectorised stream for pointwise products, the plain mapping otherwise
+    cases = [
+        f.einsum("ej,j->e", f.array("A", ("E", 35)), f.array("w", (35,))),
+        f.einsum("ej->e", f.array("A", ("E", 35))),
+        f.einsum("ej->e", f.array("A", ("E", 10))),
+        f.einsum("ej->e", f.array("A", ("E", 3))),
+        f.einsum("je->e", f.array("A", (35, "E"))),                           # summation index not contiguous
+        f.einsum("ej,ej->ej", f.array("A", ("E", 35)), f.array("B", ("E", 35))),
+        f.einsum("fej,fej->fej", f.array("A", (4, "E", 15)), f.array("B", (4, "E", 15))),
+        f.einsum("ej,ej,ej->ej", f.array("A", ("E", 3)), f.array("B", ("E", 3)), f.array("C", ("E", 3))),
+        f.einsum("ej,j->ej", f.array("A", ("E", 35)), f.array("w", (35,))),   # broadcast: not the stream path
+        f.einsum("erj,rij->ei", f.array("A", ("E", 3, 35)), f.array("D", (3, 35, 35))),   # two summation indices
+    ]
+    for expr in cases:
+        host = generate_host_input_arrays(expr, E, np_seed=E)
+        _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+    # a pointwise product on buffers that are only 8-byte aligned
+    expr = cases[5]
+    host = generate_host_input_arrays(expr, E, np_seed=1)
+    torch = torch_cuda
+    dev = {}
+    for k, v in host.items():
+        buf = torch.empty(v.size + 1, dtype=torch.float64, device="cuda")
+        buf[1:] = torch.from_numpy(v).cuda().reshape(-1)
+        dev[k] = buf[1:].view(v.shape)
+    out = f.evaluate(expr, 0, dev, wait=True)
+    _assert_close({k: v.cpu().numpy() for k, v in out.items()}, _oracle(expr, host))
+
+
 def test_outputs_are_overwritten_not_accumulated(torch_cuda):
     torch = torch_cuda
     expr = dg.grad()

@@ -34,6 +34,16 @@ cases += [(dg.grad(), ("generic",)), (dg.div(), ("generic",)), (dg.face_mass(), 
           (dg.face_mass(19), ("mfma",)), (dg.face_mass_jfi_fe(4), ("mfma",)),
           (dg.cross_product_batch(), ("mfma", "generic"))]
 cases += [(dg.batched_grad(b), ("mfma",)) for b in (3, 5)] + [(dg.batched_div(b), ("mfma",)) for b in (3, 5, 6)]
+# the other families of the reference's archive (generic einsum kernel unless noted)
+cases += [(dg.mass_apply(b, Np), ("mfma",)) for Np in (4, 10, 20, 35) for b in (4, 16)]
+cases += [(dg.operator_apply(Np), ("mfma",)) for Np in (3, 4, 6, 10, 15, 20, 35)]
+cases += [(dg.mass_apply(4), ("generic",)), (dg.operator_apply(), ("generic",))]
+for K in (4, 10, 20, 35):
+    cases += [(f.einsum("ej,j->e", f.array("A", ("E", K)), f.array("w", (K,))), ("generic",)),
+              (f.einsum("ej->e", f.array("A", ("E", K))), ("generic",)),
+              (f.einsum("ej,ej->ej", f.array("A", ("E", K)), f.array("B", ("E", K))), ("generic",))]
+cases += [(f.einsum("fej,fej->fej", f.array("A", (4, "E", K)), f.array("B", (4, "E", K))), ("generic",))
+          for K in (3, 6, 10, 15)]
 
 q = f.DeviceQueue(0)
 for expr, variants in cases:
