@@ -165,7 +165,12 @@ def barrier() -> None:
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            import torch
+
+            dist.barrier(device_ids=[torch.cuda.current_device()])   # this rank's own GPU
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device: Any = None) -> float:
