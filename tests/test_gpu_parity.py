@@ -411,3 +411,67 @@ def test_full_size_div_and_face_mass(torch_cuda, fam):
     scaled[vname] = dev[vname] * 2.0
     outs2 = f.evaluate(expr, 0, scaled, wait=True)
     assert torch.equal(outs2["_fe_out"], outs["_fe_out"] * 2.0)
+
+
+FULL_SIZE_SIBLINGS = {
+    "batched_grad_b3": lambda: dg.batched_grad(3),
+    "batched_div_b2": lambda: dg.batched_div(2),
+    "cross_product": lambda: dg.cross_product_batch(),
+    "mass_apply_b4": lambda: dg.mass_apply(4),
+    "operator_apply": lambda: dg.operator_apply(),
+    "div_components": lambda: dg.batched_div_components(),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE_SIBLINGS))
+def test_full_size_siblings(torch_cuda, name):
+    # the multi-field / planes / one-component launches at E = 1e6 (+ a ragged tail): MFMA against
+    # the generic kernels everywhere, the oracle on the first and the last 300 elements
+    torch = torch_cuda
+    from oracle import np_oracle
+
+    E = 1_000_000 + 7
+    expr = FULL_SIZE_SIBLINGS[name]()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    dev = {}
+    for arg in sorted(expr.all_args):
+        shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[arg])
+        dev[arg] = torch.rand(shape, dtype=torch.float64, device="cuda", generator=g)
+    outs = f.evaluate(expr, 0, dev, wait=True)
+    gens = f.evaluate(expr, 0, dev, transform="generic", wait=True)
+    for k in outs:
+        assert float((outs[k] - gens[k]).abs().max() / gens[k].abs().max()) <= TOL
+    del gens
+    for sl in (slice(0, 300), slice(E - 300, E)):
+        host = {}
+        for arg, t in dev.items():
+            idx = tuple(sl if isinstance(d, f.SizeParam) else slice(None) for d in expr.arg_to_shape[arg])
+            host[arg] = t[idx].cpu().numpy()
+        ref = _oracle(expr, host)
+        long_axis = [isinstance(d, f.SizeParam) for d in expr.shape].index(True)
+        for k in ref:
+            got = outs[k][(slice(None),) * long_axis + (sl,)].cpu().numpy()
+            assert np_oracle.max_rel_err(got, ref[k]) <= TOL
+
+
+def test_full_size_wave_operator(torch_cuda):
+    # one launch for div + grad + lift at E = 1e6 + 9 is bitwise the three separate launches
+    torch = torch_cuda
+    E = 1_000_000 + 9
+    exprs = [dg.div(), dg.grad(), dg.face_mass(4)]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    devs = []
+    for expr in exprs:
+        dev = {}
+        for arg in sorted(expr.all_args):
+            shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[arg])
+            dev[arg] = torch.rand(shape, dtype=torch.float64, device="cuda", generator=g)
+        devs.append(dev)
+    devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+    stages = list(zip(exprs, devs))
+    assert f.bind_operator(stages, 0).entry_points == ("fe_waveop3d_f64",)
+    fused = f.evaluate_operator(stages, 0, wait=True)
+    plain = f.evaluate_operator(stages, 0, fuse=False, wait=True)
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert torch.equal(a[k], b[k]) and bool(torch.isfinite(a[k]).all())
