@@ -165,4 +165,18 @@ __device__ __forceinline__ void balance_priority(bool younger_half, int iteratio
     }
 }
 
+// The elements behind the last full wave tile: done by block 0 before its own tiles (while its
+// first tiles stream in), with the plain per-entry code of the generic kernels (item(e, i)
+// computes output entry i of element e).  Block 0 is among the first to finish -- the older half
+// of the grid ends several us before the younger half -- so the few us this takes are hidden; a
+// separate launch for the remainder cost ~8 us, a third of a whole launch at E = 1e5.
+template <class F>
+__device__ __forceinline__ void remainder_items(int64_t e_begin, int64_t E, int Np, unsigned bid, unsigned nblk,
+                                                F item) {
+    (void)nblk;
+    if (bid != 0) return;
+    const int64_t n = (E - e_begin) * Np;
+    for (int64_t idx = threadIdx.x; idx < n; idx += blockDim.x) item(e_begin + idx / Np, (int)(idx % Np));
+}
+
 }  // namespace fe

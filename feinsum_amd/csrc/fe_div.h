@@ -108,6 +108,16 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
     const double* as_lane = asmall + g * 4 + (n & 3);
 
+    remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+        for (int k = 0; k < nb; ++k) {
+            const double* uk = field_in(P, k);
+            double* ok = field_out(P, k);
+            if (MODE == 0) div3d_item(J, D, uk, ok, E, NP, e, i, opT);
+            else if (MODE == 1) divcomp3d_item(J, D, uk, ok, E, NP, e, i, opT, jes);
+            else matapply_item(MODE == 2 ? J : nullptr, D, uk, ok, NP, e, i, opT);
+        }
+    });
+
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;

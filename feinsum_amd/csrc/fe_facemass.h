@@ -138,6 +138,15 @@ __device__ __forceinline__ void facemass_mfma_body(
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     const int64_t first = (int64_t)bid * G::WAVES + wave;
+    {
+        const int64_t jEs = jfe ? 1 : kFmNf, jFs = jfe ? E : 1;
+        const int rF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
+        const int rI = rlayout == 0 ? NFP : rlayout == 1 ? kFmNf * NFP : 1;
+        const int rJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : kFmNf * NP;
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+            facemass_item<NB>(J, R, P, E, NP, kFmNf, NFP, jEs, jFs, rF, rI, rJ, e, i);
+        });
+    }
     if (first >= tEnd) return;
 
     // prologue: units 0 and 1 of the first tile

@@ -9,13 +9,9 @@
 namespace fe {
 
 // div: out[e,i] = sum_{x,r,j} J[x,r,e] D[r,i,j] u[x,e,j]
-__global__ __launch_bounds__(256) void div3d_generic_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (E - e_begin) * Np) return;
-    const int64_t e = e_begin + idx / Np;
-    const int i = (int)(idx % Np);
+__device__ __forceinline__ void div3d_item(const double* __restrict__ J, const double* __restrict__ D,
+                                           const double* __restrict__ u, double* __restrict__ out, int64_t E,
+                                           int Np, int64_t e, int i, int opT) {
     double jac[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) jac[k] = J[(int64_t)k * E + e];
@@ -37,14 +33,18 @@ __global__ __launch_bounds__(256) void div3d_generic_kernel(
     out[e * Np + i] = acc;
 }
 
-// div component: out[e,i] = sum_{s,j} J[s,e] D[s,i,j] u[e,j]   ('se,sij,ej->ei')
-__global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
+__global__ __launch_bounds__(256) void div3d_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT, int jes) {
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (E - e_begin) * Np) return;
-    const int64_t e = e_begin + idx / Np;
-    const int i = (int)(idx % Np);
+    div3d_item(J, D, u, out, E, Np, e_begin + idx / Np, (int)(idx % Np), opT);
+}
+
+// div component: out[e,i] = sum_{s,j} J[s,e] D[s,i,j] u[e,j]   ('se,sij,ej->ei')
+__device__ __forceinline__ void divcomp3d_item(const double* __restrict__ J, const double* __restrict__ D,
+                                               const double* __restrict__ u, double* __restrict__ out,
+                                               int64_t E, int Np, int64_t e, int i, int opT, int jes) {
     const double j0 = jes ? J[e * 3 + 0] : J[0 * E + e];
     const double j1 = jes ? J[e * 3 + 1] : J[1 * E + e];
     const double j2 = jes ? J[e * 3 + 2] : J[2 * E + e];
@@ -59,14 +59,18 @@ __global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
     out[e * Np + i] = acc;
 }
 
-// element-local operator: out[e,i] = (J ? J[e] : 1) * sum_j D[i,j] u[e,j]   ('e,ij,ej->ei', 'ij,ej->ei')
-__global__ __launch_bounds__(256) void matapply_generic_kernel(
+__global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT, int jes) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (E - e_begin) * Np) return;
-    const int64_t e = e_begin + idx / Np;
-    const int i = (int)(idx % Np);
+    divcomp3d_item(J, D, u, out, E, Np, e_begin + idx / Np, (int)(idx % Np), opT, jes);
+}
+
+// element-local operator: out[e,i] = (J ? J[e] : 1) * sum_j D[i,j] u[e,j]   ('e,ij,ej->ei', 'ij,ej->ei')
+__device__ __forceinline__ void matapply_item(const double* __restrict__ J, const double* __restrict__ D,
+                                              const double* __restrict__ u, double* __restrict__ out, int Np,
+                                              int64_t e, int i, int opT) {
     const double* d = D + (opT ? i : (int64_t)i * Np);
     const int sj = opT ? Np : 1;
     const double* ue = u + e * Np;
@@ -75,16 +79,20 @@ __global__ __launch_bounds__(256) void matapply_generic_kernel(
     out[e * Np + i] = J ? J[e] * acc : acc;
 }
 
+__global__ __launch_bounds__(256) void matapply_generic_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (E - e_begin) * Np) return;
+    matapply_item(J, D, u, out, Np, e_begin + idx / Np, (int)(idx % Np), opT);
+}
+
 // face-mass: out_k[e,i] = sum_{f,j} J[e,f] R[f,i,j] v_k[f,e,j]
 //   jEs / jFs : strides of J along e and f;  rF / rI / rJ : strides of R along f, i and j
 template <int NB>
-__global__ __launch_bounds__(256) void facemass_generic_kernel(
-    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int Np,
-    int nf, int Nfp, int64_t jEs, int64_t jFs, int rF, int rI, int rJ, int64_t e_begin) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (E - e_begin) * Np) return;
-    const int64_t e = e_begin + idx / Np;
-    const int i = (int)(idx % Np);
+__device__ __forceinline__ void facemass_item(const double* __restrict__ J, const double* __restrict__ R,
+                                              const FieldPtrs& P, int64_t E, int Np, int nf, int Nfp, int64_t jEs,
+                                              int64_t jFs, int rF, int rI, int rJ, int64_t e, int i) {
     double acc[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k] = 0.0;
@@ -100,6 +108,15 @@ __global__ __launch_bounds__(256) void facemass_generic_kernel(
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) P.out[k][e * Np + i] = acc[k];
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void facemass_generic_kernel(
+    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int Np,
+    int nf, int Nfp, int64_t jEs, int64_t jFs, int rF, int rI, int rJ, int64_t e_begin) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (E - e_begin) * Np) return;
+    facemass_item<NB>(J, R, P, E, Np, nf, Nfp, jEs, jFs, rF, rI, rJ, e_begin + idx / Np, (int)(idx % Np));
 }
 
 }  // namespace fe

@@ -28,6 +28,7 @@
 // with each other after the one-time operator staging.
 #pragma once
 #include "fe_common.h"
+#include "fe_generic.h"
 
 namespace fe {
 
@@ -106,6 +107,37 @@ __device__ __forceinline__ double* grad_plane_out(const GradFields& P, int k, in
 #pragma unroll
     for (int q = 1; q < kMaxFields; ++q) p = (k == q) ? P.out[q][x] : p;
     return p;
+}
+
+// Plain VALU code, any Np: entry (e, i) of all three planes.  Correctness reference on the device,
+// the path for shapes the MFMA kernel is not compiled for, and the remainder behind the last tile.
+__device__ __forceinline__ void grad3d_item(const double* __restrict__ J, const double* __restrict__ D,
+                                            const double* __restrict__ u, double* __restrict__ out, int64_t E,
+                                            int Np, int64_t e, int i, int opT) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    const double* ue = u + e * Np;
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;   // opT: D stored as [r][j][i]
+    const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
+    const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
+    const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
+    for (int j = 0; j < Np; ++j) {
+        const double uj = ue[j];
+        t0 += d0[j * sj] * uj;
+        t1 += d1[j * sj] * uj;
+        t2 += d2[j * sj] * uj;
+    }
+    for (int x = 0; x < 3; ++x)
+        out[((int64_t)x * E + e) * Np + i] =
+            J[(int64_t)(x * 3 + 0) * E + e] * t0 + J[(int64_t)(x * 3 + 1) * E + e] * t1 +
+            J[(int64_t)(x * 3 + 2) * E + e] * t2;
+}
+
+__global__ __launch_bounds__(256) void grad3d_generic_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
+    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (E - e_begin) * Np) return;
+    grad3d_item(J, D, u, out, E, Np, e_begin + idx / Np, (int)(idx % Np), opT);
 }
 
 // wait until at most BASE + nx * PER vector-memory operations are outstanding
@@ -213,25 +245,49 @@ __device__ __forceinline__ void grad3d_mfma_body(
     }
     __syncthreads();
 
-    // ---- A fragments from the staged operator
+    // ---- A fragments from the staged operator (addresses = row part + column part: the 63
+    //      fragments of p = 4 cost one add and one LDS read each)
     double afrag[G::RT][G::KS];
     {
         const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
         const int gp = n & 3, q = n >> 2;
+        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
+        int joff[G::KS];
+        bool jok[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const int j = 4 * ks + g;
+            jok[ks] = j < NP;
+            joff[ks] = (jok[ks] ? j : 0) * jstride;
+        }
 #pragma unroll
         for (int t = 0; t < G::RT; ++t) {
             const int s = 4 * t + q;
             const int r = s % 3, i = G::TG * gp + s / 3;
+            const bool rowok = (s < 3 * G::TG) && (i < NP);
+            const double* row = dl + r * (NP * NP) + (i < NP ? i : 0) * istride;
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
-                const int j = 4 * ks + g;
-                const bool ok = (s < 3 * G::TG) && (i < NP) && (j < NP);
-                const int ic = i < NP ? i : 0, jc = j < NP ? j : 0;   // opT: D stored as [r][j][i]
-                afrag[t][ks] = ok ? dl[opT ? (r * NP + jc) * NP + ic : (r * NP + ic) * NP + jc] : 0.0;
+                const double v = row[joff[ks]];
+                afrag[t][ks] = (rowok && jok[ks]) ? v : 0.0;
             }
         }
         __syncthreads();   // the staging area becomes the waves' output buffers
     }
+
+    remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+        for (int k = 0; k < nb; ++k) {
+            const double* uk = grad_field_u(P, k);
+            if (kPlain) {
+                grad3d_item(P.j[0], D, uk, grad_plane_out(P, k, 0), E, NP, e, i, opT);
+            } else {
+                double* const o[3] = {grad_plane_out(P, k, 0), grad_plane_out(P, k, 1), grad_plane_out(P, k, 2)};
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+                    if (o[x]) divcomp3d_item(P.j[x], D, uk, o[x], E, NP, e, i, opT, 0);
+            }
+        }
+    });
 
     int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
@@ -361,32 +417,5 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
     grad3d_mfma_body<NP, M, kDbg, kPlain>(P, D, nb, nx, E, nTiles, opT, blockIdx.x, gridDim.x);
 }
 
-
-// Plain VALU kernel, any Np: one thread per (e, i), elements [e_begin, E).  Correctness reference on
-// the device and the path for shapes the MFMA kernel is not compiled for.
-__global__ __launch_bounds__(256) void grad3d_generic_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
-    double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (E - e_begin) * Np) return;
-    const int64_t e = e_begin + idx / Np;
-    const int i = (int)(idx % Np);
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    const double* ue = u + e * Np;
-    const int si = opT ? 1 : Np, sj = opT ? Np : 1;   // opT: D stored as [r][j][i]
-    const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
-    const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
-    const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
-    for (int j = 0; j < Np; ++j) {
-        const double uj = ue[j];
-        t0 += d0[j * sj] * uj;
-        t1 += d1[j * sj] * uj;
-        t2 += d2[j * sj] * uj;
-    }
-    for (int x = 0; x < 3; ++x)
-        out[((int64_t)x * E + e) * Np + i] =
-            J[(int64_t)(x * 3 + 0) * E + e] * t0 + J[(int64_t)(x * 3 + 1) * E + e] * t1 +
-            J[(int64_t)(x * 3 + 2) * E + e] * t2;
-}
 
 }  // namespace fe

@@ -102,7 +102,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, in
                 int dbg, int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::GradGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
-    *e_done = nTiles * G::TEL;
+    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
@@ -147,7 +147,7 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
                int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;
-    *e_done = nTiles * G::TEL;
+    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
@@ -184,7 +184,7 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
                    int opT, int jes, hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M, 1>;
     const int64_t nTiles = E / G::TEL;
-    *e_done = nTiles * G::TEL;
+    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
@@ -204,7 +204,7 @@ int launch_matapply_mode(const double* J, const double* D, const fe::FieldPtrs& 
                          hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M, MODE>;
     const int64_t nTiles = E / G::TEL;
-    *e_done = nTiles * G::TEL;
+    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, MODE>, G::LDS_BYTES); });
@@ -316,8 +316,7 @@ int launch_graddiv(const double* J, const double* D, const fe::GradFields& Pg, c
     using GD = fe::DivGeom<NP, MD>;
     using G = fe::GradDivGeom<NP, MG, MD>;
     const int64_t nTilesG = E / GG::TEL, nTilesD = E / GD::TEL;
-    *e_done_g = nTilesG * GG::TEL;
-    *e_done_d = nTilesD * GD::TEL;
+    *e_done_g = *e_done_d = (nTilesG > 0 || nTilesD > 0) ? E : 0;   // remainders included
     if (nTilesG == 0 && nTilesD == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] { return set_max_lds(fe::graddiv3d_mfma_kernel<NP, MG, MD>, G::LDS_BYTES); });
@@ -347,13 +346,12 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
 
 template <int NP, int NFP, int MG, int MD, int MF>
 int launch_waveop(fe::WaveOpArgs a, const fe::GradFields& Pg, const fe::FieldPtrs& Pd, const fe::FieldPtrs& Pf,
-                  int nb, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
+                  int nb, hipStream_t s, bool* launched) {
     a.nTilesG = a.E / (16 * MG);
     a.nTilesD = a.E / (16 * MD);
     a.nTilesF = a.E / (16 * MF);
-    *e_done_g = a.nTilesG * 16 * MG;
-    *e_done_d = a.nTilesD * 16 * MD;
-    if (a.nTilesG == 0 && a.nTilesD == 0 && a.nTilesF == 0) return FE_OK;
+    *launched = a.nTilesG > 0 || a.nTilesD > 0 || a.nTilesF > 0;   // remainders included
+    if (!*launched) return FE_OK;
     switch (nb) {
         case 2: return launch_waveop_nb<NP, NFP, MG, MD, MF, 2>(a, Pg, Pd, Pf, s);
         case 3: return launch_waveop_nb<NP, NFP, MG, MD, MF, 3>(a, Pg, Pd, Pf, s);
@@ -669,10 +667,9 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
     return FE_OK;
 }
 
-// tiles_done: the full MFMA tiles were covered by a fused launch; only the remainder is left
-static int facemass_impl(const double* J, const double* R, const double* const* v, double* const* out,
-                         int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
-                         int32_t layout_flags, int32_t variant, void* stream, bool tiles_done) {
+int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
+                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                    int32_t layout_flags, int32_t variant, void* stream) {
     if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
     if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
         return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
@@ -707,7 +704,7 @@ static int facemass_impl(const double* J, const double* R, const double* const* 
     const int rJ = rifj == 0 || rifj == 1 ? 1 : rifj == 2 ? Np : nf * Np;
     const bool use_mfma = variant != FE_VARIANT_GENERIC && mfma_ok;
     const int64_t nTiles = use_mfma ? E / geo.tel : 0;      // full wave tiles
-    const int64_t e_done = nTiles * geo.tel;
+    const int64_t e_done = nTiles > 0 ? E : 0;   // an MFMA launch covers the remainder too
     const int max_group = use_mfma ? geo.max_group : fe::kMaxFields;
     // fields go in groups of up to max_group per launch; never leave a group of 1 for the MFMA kernel
     for (int k0 = 0; k0 < b;) {
@@ -718,7 +715,7 @@ static int facemass_impl(const double* J, const double* R, const double* const* 
             P.v[k] = v[k0 + (k < nb ? k : 0)];
             P.out[k] = out[k0 + (k < nb ? k : 0)];
         }
-        if (nTiles > 0 && !tiles_done) {
+        if (nTiles > 0) {
             int rc = FE_OK;
             switch (Np) {   // wave tile = 16 M elements
                 case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
@@ -745,12 +742,6 @@ static int facemass_impl(const double* J, const double* R, const double* const* 
     }
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
-}
-
-int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
-                    int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
-                    int32_t layout_flags, int32_t variant, void* stream) {
-    return facemass_impl(J, R, v, out, E, Np, nf, Nfp, b, layout_flags, variant, stream, false);
 }
 
 int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, double* grad_out,
@@ -787,23 +778,21 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
     a.J = J; a.D = D; a.Jf = Jface; a.R = R; a.E = E;
     a.jfe = (fm_layout_flags & FE_FM_J_FE) ? 1 : 0;
     a.rlayout = ((fm_layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((fm_layout_flags & FE_FM_R_T) ? 2 : 0);
-    int64_t done_g = 0, done_d = 0;
+    bool launched = false;
     int rc = FE_OK;
     switch (Np) {   // the (Np, M) geometries of the three separate launches
-        case 35: rc = launch_waveop<35, 15, 1, 1, 1>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
-        case 20: rc = launch_waveop<20, 10, 2, 1, 1>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
-        case 10: rc = launch_waveop<10, 6, 3, 3, 2>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
-        default: rc = launch_waveop<4, 3, 5, 5, 4>(a, Pg, Pd, Pf, b, s, &done_g, &done_d); break;
+        case 35: rc = launch_waveop<35, 15, 1, 1, 1>(a, Pg, Pd, Pf, b, s, &launched); break;
+        case 20: rc = launch_waveop<20, 10, 2, 1, 1>(a, Pg, Pd, Pf, b, s, &launched); break;
+        case 10: rc = launch_waveop<10, 6, 3, 3, 2>(a, Pg, Pd, Pf, b, s, &launched); break;
+        default: rc = launch_waveop<4, 3, 5, 5, 4>(a, Pg, Pd, Pf, b, s, &launched); break;
     }
     if (rc != FE_OK) return rc;
-    if (done_d < E)
-        hipLaunchKernelGGL(fe::div3d_generic_kernel, dim3(generic_grid(E - done_d, Np)), dim3(256), 0, s,
-                           J, D, v_div, div_out, E, Np, done_d, 0);
-    if (done_g < E)
-        hipLaunchKernelGGL(fe::grad3d_generic_kernel, dim3(generic_grid(E - done_g, Np)), dim3(256), 0, s,
-                           J, D, u_grad, grad_out, E, Np, done_g, 0);
+    if (!launched) {   // fewer elements than any wave tile: the generic kernels
+        if (int rc2 = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc2;
+        return fe_facemass_f64(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream);
+    }
     FE_HIP_CHECK(hipGetLastError());
-    return facemass_impl(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream, true);
+    return FE_OK;
 }
 
 int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void* out,
