@@ -89,20 +89,23 @@ __device__ __forceinline__ void div3d_mfma_body(
         double* dl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D>(D, dl);
         __syncthreads();
+        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored [r][j][i]
 #pragma unroll
         for (int jq = 0; jq < G::KSJ; ++jq) {
             const int j = 4 * jq + g;
+            const double* col = dl + (j < NP ? j : 0) * jstride + n * istride;
 #pragma unroll
             for (int r = 0; r < NC; ++r)
 #pragma unroll
-                for (int t = 0; t < G::BT; ++t)
-                    abig[t][jq][r] = (j < NP) ? dl[opT ? (r * NP + j) * NP + 16 * t + n   // opT: D stored [r][j][i]
-                                                       : (r * NP + 16 * t + n) * NP + j] : 0.0;
+                for (int t = 0; t < G::BT; ++t) {
+                    const double v = col[r * (NP * NP) + 16 * t * istride];
+                    abig[t][jq][r] = (j < NP) ? v : 0.0;
+                }
         }
         for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
             const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
             const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
-            asmall[idx] = (j < NP && i < NP) ? dl[opT ? (r * NP + j) * NP + i : (r * NP + i) * NP + j] : 0.0;
+            asmall[idx] = (j < NP && i < NP) ? dl[r * (NP * NP) + i * istride + j * jstride] : 0.0;
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }

@@ -106,13 +106,11 @@ __device__ __forceinline__ void facemass_mfma_body(
         double* rl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D>(R, rl);
         __syncthreads();
-        // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i]
-        auto ridx = [&](int f, int i, int j) {
-            return rlayout == 0 ? (f * NP + i) * NFP + j
-                 : rlayout == 1 ? (i * kFmNf + f) * NFP + j
-                 : rlayout == 2 ? (f * NFP + j) * NP + i
-                                : (j * kFmNf + f) * NP + i;
-        };
+        // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i] -> strides of f, i, j
+        const int sF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
+        const int sI = rlayout == 0 ? NFP : rlayout == 1 ? kFmNf * NFP : 1;
+        const int sJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : kFmNf * NP;
+        auto ridx = [&](int f, int i, int j) { return f * sF + i * sI + j * sJ; };
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
             const int k = 4 * ks + g;
