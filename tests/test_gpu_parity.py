@@ -315,6 +315,24 @@ def test_generic_einsum_reductions_and_pointwise(torch_cuda, E):
     _assert_close({k: v.cpu().numpy() for k, v in out.items()}, _oracle(expr, host))
 
 
+@pytest.mark.parametrize("Np,Nfp", [(3, 2), (6, 3), (10, 4), (15, 5)])
+def test_two_dimensional_operators_take_the_generic_einsum_kernel(torch_cuda, Np, Nfp):
+    # triangles (ndim = 2, three faces): the same subscripts with other extents are outside the
+    # compiled families and go through the generic einsum kernel
+    import feinsum_amd as f2
+
+    E = 1003
+    grad2 = f2.einsum("xre,rij,ej->xei", f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)), f2.array("u", ("E", Np)))
+    div2 = f2.einsum("xre,rij,xej->ei", f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)),
+                     f2.array("u", (2, "E", Np)))
+    lift2 = f2.batched_einsum("ef,fij,fej->ei", [[f2.array("J", ("E", 3)), f2.array("R", (3, Np, Nfp)),
+                                                  f2.array(f"v{k}", (3, "E", Nfp))] for k in range(3)])
+    for expr in (grad2, div2, lift2):
+        assert f2.match_family(expr) is None or expr is lift2
+        host = generate_host_input_arrays(expr, E, np_seed=Np)
+        _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+
+
 def test_outputs_are_overwritten_not_accumulated(torch_cuda):
     torch = torch_cuda
     expr = dg.grad()
