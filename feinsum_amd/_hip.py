@@ -18,14 +18,15 @@ from typing import Optional, Sequence
 from feinsum_amd.diagnostics import HipLibraryError, InvalidParameterError
 
 FE_OK, FE_EINVAL, FE_EUNSUPPORTED, FE_EHIP = 0, -1, -2, -3
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA = 0, 1, 2
-VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MFMA}
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_TILED = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MFMA, "tiled": VARIANT_TILED}
 
 #: every symbol declared in include/feinsum_hip.h (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = (
     "fe_version", "fe_last_error", "fe_device_count", "fe_device_info",
     "fe_grad3d_f64", "fe_div3d_f64", "fe_grad3d_f64_ex", "fe_div3d_f64_ex", "fe_divcomp3d_f64",
     "fe_grad3d_batched_f64", "fe_div3d_batched_f64", "fe_gradplanes3d_f64", "fe_matapply_f64",
+    "fe_grad_f64", "fe_div_f64",
     "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
@@ -45,6 +46,7 @@ class ArgPack(C.Structure):
         ("Np", C.c_int32), ("nf", C.c_int32), ("Nfp", C.c_int32), ("b", C.c_int32),
         ("layout_flags", C.c_int32), ("variant", C.c_int32),
         ("j3", C.POINTER(C.c_void_p)),
+        ("ndim", C.c_int32),
     ]
 
 
@@ -112,6 +114,11 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                        C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    for name in ("fe_grad_f64", "fe_div_f64"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                       C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_matapply_f64.restype = C.c_int
     lib.fe_matapply_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]

@@ -17,6 +17,7 @@
 #include "fe_fused.h"
 #include "fe_generic.h"
 #include "fe_grad.h"
+#include "fe_tiled.h"
 
 namespace {
 
@@ -95,6 +96,54 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
     int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
     const int64_t cap = (8 / wavesPerBlock) * (int64_t)device_cu_count();   // 8 waves per CU
     return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+// ---- the LDS-tiled VALU kernel (fe_tiled.h): any shape whose operator fits in LDS
+constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
+
+bool tiled_fits(fe::TiledArgs a) { return a.Np >= 1 && a.Np <= fe::kTiledThreads && fe::tiled_plan(a) <= kTiledMaxLds; }
+
+int launch_tiled(fe::TiledArgs a, hipStream_t s) {
+    const int64_t lds = fe::tiled_plan(a);
+    if (a.Np > fe::kTiledThreads || lds > kTiledMaxLds)
+        return fail(FE_EUNSUPPORTED, "tiled kernel: operator and tile need %lld bytes of LDS (limit %lld)",
+                    (long long)lds, (long long)kTiledMaxLds);
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::tiled_apply_kernel, (int)kTiledMaxLds); });
+    if (attr_rc != FE_OK) return attr_rc;
+    const int64_t nTiles = (a.E + a.TE - 1) / a.TE;
+    int64_t per_cu = kTiledMaxLds / lds;   // resident blocks per CU: LDS, and 2048 threads
+    if (per_cu > 2048 / fe::kTiledThreads) per_cu = 2048 / fe::kTiledThreads;
+    const int64_t cap = per_cu * device_cu_count();
+    hipLaunchKernelGGL(fe::tiled_apply_kernel, dim3((unsigned)(nTiles < cap ? nTiles : cap)), dim3(fe::kTiledThreads),
+                       (size_t)lds, s, a);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
+
+// Which kernel class serves a call.  AUTO: MFMA where compiled, else the tiled kernel where the
+// operator fits in LDS, else the plain generic kernels.
+enum KernelPath { kPathGeneric, kPathMfma, kPathTiled };
+int choose_path(int variant, bool mfma_ok, bool tiled_ok, const char* what, int Np, KernelPath* path) {
+    if (variant == FE_VARIANT_GENERIC) { *path = kPathGeneric; return FE_OK; }
+    if (variant == FE_VARIANT_TILED) {
+        if (!tiled_ok) return fail(FE_EUNSUPPORTED, "%s: the tiled kernel does not fit this shape in LDS (Np=%d)", what, Np);
+        *path = kPathTiled;
+        return FE_OK;
+    }
+    if (variant == FE_VARIANT_MFMA && !mfma_ok)
+        return fail(FE_EUNSUPPORTED, "%s: MFMA variant is not compiled for this shape (Np=%d)", what, Np);
+    *path = mfma_ok ? kPathMfma : tiled_ok ? kPathTiled : kPathGeneric;
+    return FE_OK;
+}
+
+fe::TiledArgs tiled_args(int family, const double* J, const double* A, const fe::FieldPtrs& P, int nb, int64_t E,
+                         int ndim, int Np, int nf, int Nfp, int opT, int jlayout, int rlayout) {
+    fe::TiledArgs a = {};
+    a.J = J; a.A = A; a.P = P; a.E = E; a.family = family;
+    a.ndim = ndim; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.nb = nb;
+    a.opT = opT; a.jlayout = jlayout; a.rlayout = rlayout;
+    return a;
 }
 
 template <int NP, int M>
@@ -273,10 +322,16 @@ fe::GradFields grad_fields(const double* J, const double* const* u, double* cons
 int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const double* D, int nb, int nx,
                        int64_t E, int Np, int opT, int variant, hipStream_t s) {
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "grad: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
+    fe::FieldPtrs Pt = {};
+    for (int k = 0; k < nb; ++k) { Pt.v[k] = P.u[k]; Pt.out[k] = P.out[k][0]; }
+    const fe::TiledArgs ta = tiled_args(FE_FAMILY_GRAD, Jfull, D, Pt, nb, E, 3, Np, 0, 0, opT, 0, 0);
+    KernelPath path;
+    if (int rc = choose_path(variant >= 1000 ? FE_VARIANT_MFMA : variant, mfma_ok, Jfull && tiled_fits(ta), "grad", Np,
+                             &path))
+        return rc;
+    if (path == kPathTiled) return launch_tiled(ta, s);
     int64_t e_done = 0;
-    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+    if (path == kPathMfma) {
         int dbg = 0;
 #ifdef FE_EXPERIMENTS
         if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
@@ -443,9 +498,9 @@ int fe_grad3d_batched_f64(const double* J, const double* D, const double* const*
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
-    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
+    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_TILED && variant < 1000))
 #else
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
 #endif
         return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
     if (E == 0) return FE_OK;
@@ -464,7 +519,7 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* 
                                    op_flags, variant, stream);
     }
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad planes: bad operator flags %d", op_flags);
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "grad planes: unknown variant %d", variant);
     fe::GradFields P = {};
     int nx = -1;
@@ -523,18 +578,21 @@ int fe_div3d_batched_f64(const double* J, const double* D, const double* const* 
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "div: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
-    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA && variant < 1000))
+    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_TILED && variant < 1000))
 #else
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
 #endif
         return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "div: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
+    const fe::TiledArgs ta = tiled_args(FE_FAMILY_DIV, J, D, P, b, E, 3, Np, 0, 0, opT, 0, 0);
+    KernelPath path;
+    if (int rc = choose_path(variant >= 1000 ? FE_VARIANT_MFMA : variant, mfma_ok, tiled_fits(ta), "div", Np, &path))
+        return rc;
+    if (path == kPathTiled) return launch_tiled(ta, s);
     int64_t e_done = 0;
-    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+    if (path == kPathMfma) {
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
@@ -553,21 +611,65 @@ int fe_div3d_batched_f64(const double* J, const double* D, const double* const* 
     return FE_OK;
 }
 
+// grad / div of ndim-dimensional elements: ndim = 3 is the 3d entry point; ndim = 2 (triangles)
+// runs on the tiled kernel.
+static int nd_launch(int family, const char* what, const double* J, const double* D, const double* const* u,
+                     double* const* out, int64_t E, int32_t ndim, int32_t Np, int32_t b, int32_t op_flags,
+                     int32_t variant, void* stream) {
+    if (ndim != 2) return fail(FE_EUNSUPPORTED, "%s: ndim must be 2 or 3 (got %d)", what, ndim);
+    if (!u || !out) return fail(FE_EINVAL, "%s: null pointer table", what);
+    if (b < 1) return fail(FE_EINVAL, "%s: b=%d, need at least one field", what, b);
+    if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "%s: bad operator flags %d", what, op_flags);
+    if (variant != FE_VARIANT_AUTO && variant != FE_VARIANT_TILED)
+        return fail(FE_EUNSUPPORTED, "%s: only the tiled kernel serves ndim = 2 (variant %d)", what, variant);
+    for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {
+        const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
+        fe::FieldPtrs P = {};
+        for (int k = 0; k < nb; ++k) {
+            if (int rc = check_common(J, D, u[k0 + k], out[k0 + k], E, Np)) return rc;
+            P.v[k] = u[k0 + k];
+            P.out[k] = out[k0 + k];
+        }
+        if (E == 0) continue;
+        if (int rc = launch_tiled(tiled_args(family, J, D, P, nb, E, ndim, Np, 0, 0, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0,
+                                             0, 0), static_cast<hipStream_t>(stream)))
+            return rc;
+    }
+    return FE_OK;
+}
+
+int fe_grad_f64(const double* J, const double* D, const double* const* u, double* const* out, int64_t E,
+                int32_t ndim, int32_t Np, int32_t b, int32_t op_flags, int32_t variant, void* stream) {
+    if (ndim == 3) return fe_grad3d_batched_f64(J, D, u, out, E, Np, b, op_flags, variant, stream);
+    return nd_launch(FE_FAMILY_GRAD, "grad", J, D, u, out, E, ndim, Np, b, op_flags, variant, stream);
+}
+
+int fe_div_f64(const double* J, const double* D, const double* const* u, double* const* out, int64_t E,
+               int32_t ndim, int32_t Np, int32_t b, int32_t op_flags, int32_t variant, void* stream) {
+    if (ndim == 3) return fe_div3d_batched_f64(J, D, u, out, E, Np, b, op_flags, variant, stream);
+    return nd_launch(FE_FAMILY_DIV, "div", J, D, u, out, E, ndim, Np, b, op_flags, variant, stream);
+}
+
 int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
                      int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
     if (int rc = check_common(J, D, u, out, E, Np)) return rc;
     if (op_flags & ~(FE_OP_TRANSPOSED | FE_OP_J_ES))
         return fail(FE_EINVAL, "div component: bad operator flags %d", op_flags);
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "div component: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, jes = (op_flags & FE_OP_J_ES) ? 1 : 0;
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "div component: MFMA variant is compiled for Np in {4, 10, 20, 35} (Np=%d)", Np);
+    fe::FieldPtrs Pt = {};
+    Pt.v[0] = u;
+    Pt.out[0] = out;
+    const fe::TiledArgs ta = tiled_args(FE_FAMILY_DIVCOMP, J, D, Pt, 1, E, 3, Np, 0, 0, opT, jes, 0);
+    KernelPath path;
+    if (int rc = choose_path(variant, mfma_ok, tiled_fits(ta), "div component", Np, &path)) return rc;
+    if (path == kPathTiled) return launch_tiled(ta, s);
     int64_t e_done = 0;
-    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+    if (path == kPathMfma) {
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
             case 35: rc = launch_divcomp<35, 1>(J, D, u, out, E, opT, jes, s, &e_done); break;
@@ -600,16 +702,18 @@ int fe_matapply_f64(const double* J, const double* D, const double* const* u, do
         P.out[k] = out[k];
     }
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "matapply: bad operator flags %d", op_flags);
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "matapply: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 15 || Np == 10 || Np == 6 || Np == 4 || Np == 3;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED, "matapply: MFMA variant is compiled for Np in {3, 4, 6, 10, 15, 20, 35} (Np=%d)", Np);
+    const fe::TiledArgs ta = tiled_args(FE_FAMILY_MATAPPLY, J, D, P, b, E, 1, Np, 0, 0, opT, 0, 0);
+    KernelPath path;
+    if (int rc = choose_path(variant, mfma_ok, tiled_fits(ta), "matapply", Np, &path)) return rc;
+    if (path == kPathTiled) return launch_tiled(ta, s);
     int64_t e_done = 0;
-    if (variant != FE_VARIANT_GENERIC && mfma_ok) {
+    if (path == kPathMfma) {
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements: a few KB per tile at every order
             case 35: rc = launch_matapply<35, 2>(J, D, P, b, E, opT, s, &e_done); break;
@@ -635,10 +739,10 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
                      void* stream) {
     if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
     if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "graddiv: unknown variant %d", variant);
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
-    if (variant == FE_VARIANT_GENERIC || !mfma_ok) {
+    if ((variant != FE_VARIANT_AUTO && variant != FE_VARIANT_MFMA) || !mfma_ok) {
         // two launches back to back on the stream
         if (int rc = fe_div3d_f64(J, D, v_div, div_out, E, Np, variant, stream)) return rc;
         return fe_grad3d_f64(J, D, u_grad, grad_out, E, Np, variant, stream);
@@ -675,7 +779,7 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
         return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
                     Nfp, b);
     if (layout_flags & ~7) return fail(FE_EINVAL, "face-mass: bad layout flags %d", layout_flags);
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "face-mass: unknown variant %d", variant);
     if (!v || !out) return fail(FE_EINVAL, "face-mass: null pointer table");
     if (E == 0) return FE_OK;
@@ -692,17 +796,35 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
 
     FmChoice geo{0, 16};
     const bool mfma_ok = fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2;
-    if (variant == FE_VARIANT_MFMA && !mfma_ok)
-        return fail(FE_EUNSUPPORTED,
-                    "face-mass: MFMA variant is compiled for nf=4, (Np,Nfp) in {(4,3),(10,6),(20,10),(35,15)}, b >= 2");
     const int jfe = (layout_flags & FE_FM_J_FE) ? 1 : 0;
     // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i]
     const int rifj = ((layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((layout_flags & FE_FM_R_T) ? 2 : 0);
+    KernelPath path;
+    {
+        fe::FieldPtrs none = {};
+        const fe::TiledArgs probe = tiled_args(FE_FAMILY_FACEMASS, J, R, none, 1, E, 3, Np, nf, Nfp, 0, jfe, rifj);
+        // below ~10 rows the tiled kernel has too few busy lanes to beat the plain one (measured:
+        // triangles p = 2, Np = 6: 1.4 vs 2.2 TFLOP/s; p = 4, Np = 15: 3.1 vs 2.6)
+        const bool tiled_ok = tiled_fits(probe) && (variant == FE_VARIANT_TILED || Np >= 10);
+        if (int rc = choose_path(variant, mfma_ok, tiled_ok, "face-mass (MFMA: nf = 4, tetrahedral p = 1..4, b >= 2)", Np,
+                                 &path))
+            return rc;
+    }
+    if (path == kPathTiled) {   // groups of up to kMaxFields fields share the staged operator
+        for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {
+            const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
+            fe::FieldPtrs P = {};
+            for (int k = 0; k < nb; ++k) { P.v[k] = v[k0 + k]; P.out[k] = out[k0 + k]; }
+            if (int rc = launch_tiled(tiled_args(FE_FAMILY_FACEMASS, J, R, P, nb, E, 3, Np, nf, Nfp, 0, jfe, rifj), s))
+                return rc;
+        }
+        return FE_OK;
+    }
     const int64_t jEs = jfe ? 1 : nf, jFs = jfe ? E : 1;
     const int rF = rifj == 0 ? Np * Nfp : rifj == 1 ? Nfp : rifj == 2 ? Nfp * Np : Np;
     const int rI = rifj == 0 ? Nfp : rifj == 1 ? nf * Nfp : 1;
     const int rJ = rifj == 0 || rifj == 1 ? 1 : rifj == 2 ? Np : nf * Np;
-    const bool use_mfma = variant != FE_VARIANT_GENERIC && mfma_ok;
+    const bool use_mfma = path == kPathMfma;
     const int64_t nTiles = use_mfma ? E / geo.tel : 0;      // full wave tiles
     const int64_t e_done = nTiles > 0 ? E : 0;   // an MFMA launch covers the remainder too
     const int max_group = use_mfma ? geo.max_group : fe::kMaxFields;
@@ -749,7 +871,7 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
                     const double* const* f, double* const* lift, int64_t E, int32_t Np, int32_t nf,
                     int32_t Nfp, int32_t b, int32_t fm_layout_flags, int32_t variant, void* stream) {
     FmChoice geo{0, 16};
-    const bool fused = variant != FE_VARIANT_GENERIC && fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
+    const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
                        b <= 4 && f && lift && E > 0 && !(fm_layout_flags & ~7);
     if (!fused) {   // three launches (argument checks included)
         if (int rc = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc;
@@ -757,7 +879,7 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
     }
     if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
     if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "waveop: unknown variant %d", variant);
     if (!Jface || !R) return fail(FE_EINVAL, "waveop: null device pointer");
     uintptr_t bits = reinterpret_cast<uintptr_t>(Jface) | reinterpret_cast<uintptr_t>(R);
@@ -889,11 +1011,15 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
 static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
     switch (family) {
         case FE_FAMILY_GRAD:
+            if (a->ndim == 2)
+                return fe_grad_f64(a->J, a->D, a->v, a->outs, a->E, 2, a->Np, a->b, a->layout_flags, a->variant, stream);
             if (a->b > 1)
                 return fe_grad3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
                                              a->variant, stream);
             return fe_grad3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_DIV:
+            if (a->ndim == 2)
+                return fe_div_f64(a->J, a->D, a->v, a->outs, a->E, 2, a->Np, a->b, a->layout_flags, a->variant, stream);
             if (a->b > 1)
                 return fe_div3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
                                             a->variant, stream);

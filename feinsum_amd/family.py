@@ -122,9 +122,10 @@ def match_family(einsum: BatchedEinsum) -> Optional[KernelPlan]:
         if any(isinstance(dim(t), SizeParam) for t in fixed):
             continue
         if family in (FAMILY_GRAD, FAMILY_DIV):
-            if int(dim("x")) != 3 or int(dim("r")) != 3 or int(dim("i")) != int(dim("j")):
+            # tetrahedra (ndim = 3) and triangles (ndim = 2)
+            if int(dim("x")) not in (2, 3) or int(dim("r")) != int(dim("x")) or int(dim("i")) != int(dim("j")):
                 continue
-            params = {"Np": int(dim("i"))}
+            params = {"Np": int(dim("i")), "ndim": int(dim("x"))}
         elif family == FAMILY_DIVCOMP:
             if int(dim("r")) != 3 or int(dim("i")) != int(dim("j")):
                 continue

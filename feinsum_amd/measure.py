@@ -249,7 +249,7 @@ class _FamilyLaunch:
             self._keep += (va, oa)
             pack.v, pack.outs = va, oa
             pack.E, pack.Np = self.E, p["Np"]
-            pack.nf, pack.Nfp = p.get("nf", 0), p.get("Nfp", 0)
+            pack.nf, pack.Nfp, pack.ndim = p.get("nf", 0), p.get("Nfp", 0), p.get("ndim", 3)
             pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
             self.groups.append(pack)
             k = k2
@@ -293,11 +293,11 @@ class _FamilyLaunch:
                 _hip.check(lib.fe_gradplanes3d_f64(pack.j3, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                    pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_GRAD:
-                _hip.check(lib.fe_grad3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
-                                                     pack.b, pack.layout_flags, pack.variant, stream_ptr))
+                _hip.check(lib.fe_grad_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.ndim, pack.Np,
+                                           pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIV:
-                _hip.check(lib.fe_div3d_batched_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
-                                                    pack.b, pack.layout_flags, pack.variant, stream_ptr))
+                _hip.check(lib.fe_div_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.ndim, pack.Np,
+                                          pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_MATAPPLY:
                 _hip.check(lib.fe_matapply_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np, pack.b,
                                                pack.layout_flags, pack.variant, stream_ptr))

@@ -65,7 +65,8 @@ class _WaveOpLaunch:
 
 def _single_plain_group(b: Any, family: int) -> bool:
     return (isinstance(b, _FamilyLaunch) and b.plan.family == family and len(b.groups) == 1
-            and (family == FAMILY_FACEMASS or (b.groups[0].b == 1 and b.plan.layout_flags == 0)))
+            and (family == FAMILY_FACEMASS
+                 or (b.groups[0].b == 1 and b.plan.layout_flags == 0 and b.groups[0].ndim == 3)))
 
 
 def _merge(bound: List[Any]) -> List[Any]:

@@ -46,7 +46,7 @@ logger = logging.getLogger(__name__)
 DEFAULT_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
                           "transform_archive_mi355x.sqlite")
 TIMINGS_TABLENAME = "FEINSUM_TIMING_FACTS"
-KNOWN_VARIANTS = ("mfma", "generic")
+KNOWN_VARIANTS = ("mfma", "tiled", "generic")
 
 
 # -- column encodings (reference: sql_utils.py:54-130) ------------------------------------

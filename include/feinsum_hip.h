@@ -30,7 +30,7 @@
  *
  * `variant` selects the kernel implementation (the build's replacement for the
  * reference's transform archive lookup, sql_utils.py:247-294):
- *   FE_VARIANT_AUTO    best available kernel for (Np, alignment)
+ *   FE_VARIANT_AUTO    best available kernel: MFMA where compiled, else tiled, else generic
  *   FE_VARIANT_GENERIC plain one-thread-per-output VALU kernel, any Np
  *   FE_VARIANT_MFMA    LDS-staged fp64-MFMA kernel (needs Np == 35 etc.;
  *                      FE_EUNSUPPORTED if the shape is not compiled)
@@ -53,6 +53,7 @@ extern "C" {
 #define FE_VARIANT_AUTO    0
 #define FE_VARIANT_GENERIC 1
 #define FE_VARIANT_MFMA    2
+#define FE_VARIANT_TILED   3  /* LDS-tiled VALU kernel, any shape whose operator fits in LDS */
 
 /* families, for fe_time_launches / fe_flops_per_element */
 #define FE_FAMILY_GRAD     1
@@ -140,6 +141,21 @@ int fe_div3d_batched_f64(const double* J, const double* D,
                          int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                          int32_t variant, void* stream);
 
+/* grad / div of ndim-dimensional simplices, b fields sharing J and D:
+ *   J [ndim][ndim][E]   D [ndim][Np][Np]   grad: u_k [E][Np] -> out_k [ndim][E][Np]
+ *                                           div:  u_k [ndim][E][Np] -> out_k [E][Np]
+ * ndim == 3 is fe_grad3d_batched_f64 / fe_div3d_batched_f64; ndim == 2 (triangles: the same
+ * transforms with ndim = 2, tuning/impls/xre_rij_ej_to_xei.py:20-22 `ndim = e.shape[0]`) runs on
+ * the LDS-tiled kernel (FE_VARIANT_AUTO / FE_VARIANT_TILED). */
+int fe_grad_f64(const double* J, const double* D,
+                const double* const* u, double* const* out,
+                int64_t E, int32_t ndim, int32_t Np, int32_t b, int32_t op_flags,
+                int32_t variant, void* stream);
+int fe_div_f64(const double* J, const double* D,
+               const double* const* u, double* const* out,
+               int64_t E, int32_t ndim, int32_t Np, int32_t b, int32_t op_flags,
+               int32_t variant, void* stream);
+
 /* grad-type batch over separate geometry-factor arrays and output planes:
  *   out[3k + x][e,i] = sum_{r,j} J3[x][r,e] * D[r,i,j] * u[k][e,j],  k = 0..b-1, x = 0..2
  * i.e. the rows of a batched 're,rij,ej->ei' / 're,rji,ej->ei' that share u[k] and D are
@@ -218,6 +234,7 @@ typedef struct fe_argpack {
     int64_t E;
     int32_t Np, nf, Nfp, b, layout_flags, variant;   /* layout_flags: FE_FM_* or FE_OP_* by family */
     const double* const* j3;  /* FE_FAMILY_GRADPLANES: 3 ptrs; v = u (b), outs = planes (3 b) */
+    int32_t ndim;             /* grad / div: 0 or 3 = tetrahedra, 2 = triangles (v / outs, any b) */
 } fe_argpack;
 
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed

@@ -14,7 +14,7 @@ import dg
 
 def test_basic_matches():
     p = f.match_family(dg.grad())
-    assert p.family == FAMILY_GRAD and p.params == {"Np": 35} and p.long_index == "e"
+    assert p.family == FAMILY_GRAD and p.params == {"Np": 35, "ndim": 3} and p.long_index == "e"
     assert p.roles == {"J": 0, "D": 1, "u": 2}
     p = f.match_family(dg.div())
     assert p.family == FAMILY_DIV
@@ -24,7 +24,7 @@ def test_basic_matches():
     p = f.match_family(dg.face_mass_ifj_fe())
     assert p.family == FAMILY_FACEMASS and p.layout_flags == (FM_J_FE | FM_R_IFJ)
     assert p.roles == {"J": 1, "R": 0, "v": 2}
-    assert f.match_family(dg.grad(10)).params == {"Np": 10}
+    assert f.match_family(dg.grad(10)).params == {"Np": 10, "ndim": 3}
 
 
 def test_non_family():
@@ -38,10 +38,16 @@ def test_non_family():
     g32 = f.einsum("xre,rij,ej->xei", f.array("J", (3, 3, "E"), "float32"),
                    f.array("R", (3, 35, 35), "float32"), f.array("u", ("E", 35), "float32"))
     assert f.match_family(g32) is None
-    # 2D grad (ndim = 2) is not the 3D kernel
+    # 2D grad (ndim = 2) is the grad family with ndim = 2 (tiled kernel); other ndim are not
     g2 = f.einsum("xre,rij,ej->xei", f.array("J", (2, 2, "E")), f.array("R", (2, 10, 10)),
                   f.array("u", ("E", 10)))
-    assert f.match_family(g2) is None
+    assert f.match_family(g2).params == {"Np": 10, "ndim": 2}
+    g4 = f.einsum("xre,rij,ej->xei", f.array("J", (4, 4, "E")), f.array("R", (4, 10, 10)),
+                  f.array("u", ("E", 10)))
+    assert f.match_family(g4) is None
+    g23 = f.einsum("xre,rij,ej->xei", f.array("J", (2, 3, "E")), f.array("R", (3, 10, 10)),
+                   f.array("u", ("E", 10)))
+    assert f.match_family(g23) is None
 
 
 def test_renaming_and_operand_order_fuzz():

@@ -316,9 +316,9 @@ def test_generic_einsum_reductions_and_pointwise(torch_cuda, E):
 
 
 @pytest.mark.parametrize("Np,Nfp", [(3, 2), (6, 3), (10, 4), (15, 5)])
-def test_two_dimensional_operators_take_the_generic_einsum_kernel(torch_cuda, Np, Nfp):
-    # triangles (ndim = 2, three faces): the same subscripts with other extents are outside the
-    # compiled families and go through the generic einsum kernel
+def test_two_dimensional_operators(torch_cuda, Np, Nfp):
+    # triangles (ndim = 2, three faces): grad / div on the tiled kernel (fe_grad_f64 / fe_div_f64),
+    # the lift on the face-mass entry point with nf = 3
     import feinsum_amd as f2
 
     E = 1003
@@ -327,10 +327,40 @@ def test_two_dimensional_operators_take_the_generic_einsum_kernel(torch_cuda, Np
                      f2.array("u", (2, "E", Np)))
     lift2 = f2.batched_einsum("ef,fij,fej->ei", [[f2.array("J", ("E", 3)), f2.array("R", (3, Np, Nfp)),
                                                   f2.array(f"v{k}", (3, "E", Nfp))] for k in range(3)])
-    for expr in (grad2, div2, lift2):
-        assert f2.match_family(expr) is None or expr is lift2
+    bgrad2 = f2.batched_einsum("xre,rji,ej->xei", [[f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)),
+                                                    f2.array(f"u{k}", ("E", Np))] for k in range(3)])
+    for expr in (grad2, div2, lift2, bgrad2):
+        assert f2.match_family(expr) is not None
         host = generate_host_input_arrays(expr, E, np_seed=Np)
-        _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+        ref = _oracle(expr, host)
+        _assert_close(_run(torch_cuda, expr, host), ref)
+        _assert_close(_run(torch_cuda, expr, host, transform="tiled"), ref)
+
+
+@pytest.mark.parametrize("Np,Nfp", [(4, 3), (20, 10), (35, 15), (56, 21)])
+@pytest.mark.parametrize("E", [1, 63, 64, 65, 1003, 5000])
+def test_tiled_kernel_all_families(torch_cuda, Np, Nfp, E):
+    # the LDS-tiled VALU kernel at compiled orders (forced), at p = 5 and p = 6 (what AUTO picks
+    # there), partial tiles included
+    exprs = [dg.grad(Np), dg.div(Np), dg.grad_t(Np), dg.div_t(Np), dg.batched_grad(3, Np), dg.batched_div(2, Np),
+             dg.face_mass(4, Np=Np, Nfp=Nfp), dg.face_mass_ifj_fe(3, Np=Np, Nfp=Nfp),
+             dg.face_mass_jfi_fe(2, Np=Np, Nfp=Nfp), dg.face_mass_fji(9, Np=Np, Nfp=Nfp),
+             dg.mass_apply(4, Np), dg.operator_apply(Np, "ji"), dg.batched_div_components(Np)]
+    for expr in exprs:
+        host = generate_host_input_arrays(expr, E, np_seed=Np + E)
+        ref = _oracle(expr, host)
+        _assert_close(_run(torch_cuda, expr, host, transform="tiled"), ref)
+        if Np > 35:
+            _assert_close(_run(torch_cuda, expr, host), ref)
+
+
+def test_tiled_kernel_that_does_not_fit_falls_back(torch_cuda):
+    # 3 x 150 x 150 doubles = 540 KB: no room in LDS; AUTO takes the generic kernel, "tiled" refuses
+    expr = dg.grad(150)
+    host = generate_host_input_arrays(expr, 70, np_seed=1)
+    _assert_close(_run(torch_cuda, expr, host), _oracle(expr, host))
+    with pytest.raises(NotImplementedError, match="LDS"):
+        _run(torch_cuda, expr, host, transform="tiled")
 
 
 def test_outputs_are_overwritten_not_accumulated(torch_cuda):
