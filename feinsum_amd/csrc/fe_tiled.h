@@ -19,8 +19,10 @@
 //       div comp. B[e, (s, j)]  = J[s, e] u[e, j]                  (K = 3 Np)
 //       operator  B[e, j]       = J[e] u[e, j]  or  u[e, j]        (K = Np)
 //       face-mass B[e, (f, j)]  = J[e, f] v[f, e, j]               (K = nf Nfp)
-// * thread (i, g) owns output row i for the EB = 8 elements of element group g: one A value and
-//   EB broadcast B values feed EB (grad: ndim EB) FMAs;
+// * thread (i, g) owns three accumulator rows for the EB (8, or 4 when LDS is tight) elements of
+//   element group g -- grad: row i of the ndim operator components; the others: output rows i,
+//   i + IW, i + 2 IW (IW = ceil(Np / 3)) -- so three A values and EB broadcast B values feed 3 EB
+//   FMAs;
 // * grad's epilogue contracts the ndim accumulators with J[x, r, e] (staged per tile too).
 // Partial last tiles are handled by guards, so there is no remainder path.
 #pragma once
@@ -29,7 +31,7 @@
 
 namespace fe {
 
-constexpr int kTiledEB = 8;          // elements per thread
+constexpr int kTiledRows = 3;        // accumulator rows per thread
 constexpr int kTiledThreads = 512;
 constexpr int kTiledMaxGroups = 64;  // element groups per tile
 constexpr int64_t kTiledLdsBudget = 160 * 1024;
@@ -42,7 +44,7 @@ struct TiledArgs {
     int family;          // FE_FAMILY_GRAD / DIV / DIVCOMP / MATAPPLY / FACEMASS
     int ndim, Np, nf, Nfp, nb;
     int opT, jlayout, rlayout;   // transposed operator; J as 'es' (div comp.) / 'fe' (face-mass); R layout 0..3
-    int ncomp, K, KP, neg, TE;   // derived by tiled_plan()
+    int ncomp, K, KP, IW, EB, neg, TE, At_d;   // derived by tiled_plan()
 };
 
 // LDS bytes of a launch (operator + B tile + J tile), after filling in the derived fields.
@@ -53,46 +55,58 @@ inline int64_t tiled_plan(TiledArgs& a) {
         : a.family == FE_FAMILY_DIVCOMP ? 3 * a.Np
                                         : a.nf * a.Nfp;
     a.KP = a.K | 1;   // odd row stride: the element groups of a wave hit different banks
-    a.neg = kTiledThreads / a.Np;
-    if (a.neg > kTiledMaxGroups) a.neg = kTiledMaxGroups;
-    if (a.neg < 1) a.neg = 1;
+    // lanes per element group: grad keeps row i of all components, the others three rows each
+    a.IW = a.family == FE_FAMILY_GRAD ? a.Np : (a.Np + kTiledRows - 1) / kTiledRows;
     const int64_t jrows = a.family == FE_FAMILY_GRAD || a.family == FE_FAMILY_DIV ? (int64_t)a.ndim * a.ndim : 0;
-    const int64_t op_bytes = 8 * (int64_t)a.ncomp * a.K * a.Np;
-    const int64_t group_bytes = 8 * (int64_t)kTiledEB * (a.KP + jrows);   // B rows + J columns of one element group
-    // fewer element groups per tile when the operator leaves little room (e.g. div at p = 5)
-    while (a.neg > 1 && op_bytes + a.neg * group_bytes > kTiledLdsBudget) --a.neg;
-    a.TE = a.neg * kTiledEB;
-    return op_bytes + a.neg * group_bytes;
+    a.At_d = a.ncomp * a.K * a.Np + kTiledRows * a.IW;   // + slack: rows i >= Np are read, never stored
+    a.At_d += a.At_d & 1;
+    const int64_t op_bytes = 8 * (int64_t)a.At_d;
+    int64_t bytes = 0;
+    for (a.EB = 8; a.EB >= 4; a.EB /= 2) {
+        const int64_t group_bytes = 8 * (int64_t)a.EB * (a.KP + jrows);   // B rows + J columns of one element group
+        a.neg = kTiledThreads / a.IW;
+        if (a.neg > kTiledMaxGroups) a.neg = kTiledMaxGroups;
+        if (a.neg < 1) a.neg = 1;
+        const int want = a.neg;
+        // fewer element groups per tile when the operator leaves little room (e.g. div at p = 5)
+        while (a.neg > 1 && op_bytes + a.neg * group_bytes > kTiledLdsBudget) --a.neg;
+        bytes = op_bytes + a.neg * group_bytes;
+        if (2 * a.neg >= want) break;   // at least half of the lanes busy; else try smaller groups
+    }
+    if (a.EB < 4) a.EB = 4;
+    a.TE = a.neg * a.EB;
+    return bytes;
 }
 
-// acc[c][b] = sum_k A_c[i, k] B[e_b, k]: ap -> At[0][0][i] (component stride K Np, k stride Np),
-// bp -> the thread's first B row (row stride KP, all lanes of an element group read one address)
-template <int NC>
-__device__ __forceinline__ void tiled_gemm(const double* ap, const double* bp, int K, int Np, int KP,
-                                           double (&acc)[3][kTiledEB]) {
+// acc[c][b] = sum_k A[row c of this thread, k] B[e_b, k]: ap -> At[0][0][i] (k stride Np; the thread's
+// rows are row_stride apart: K Np between grad's components, IW between output rows), bp -> the
+// thread's first B row (row stride KP, all lanes of an element group read one address)
+template <int NC, int EB>
+__device__ __forceinline__ void tiled_gemm(const double* ap, int row_stride, const double* bp, int K, int Np, int KP,
+                                           double (&acc)[kTiledRows][EB]) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < kTiledRows; ++c)
 #pragma unroll
-        for (int b = 0; b < kTiledEB; ++b) acc[c][b] = 0.0;
-    const int cs = K * Np;
+        for (int b = 0; b < EB; ++b) acc[c][b] = 0.0;
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
-        double bv[kTiledEB], av[NC];
+        double bv[EB], av[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) av[c] = ap[c * cs + k * Np];
+        for (int c = 0; c < NC; ++c) av[c] = ap[c * row_stride + k * Np];
 #pragma unroll
-        for (int b = 0; b < kTiledEB; ++b) bv[b] = bp[b * KP + k];
+        for (int b = 0; b < EB; ++b) bv[b] = bp[b * KP + k];
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int b = 0; b < kTiledEB; ++b) acc[c][b] += av[c] * bv[b];
+            for (int b = 0; b < EB; ++b) acc[c][b] += av[c] * bv[b];
     }
 }
 
+template <int EB>
 __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a) {
     extern __shared__ __attribute__((aligned(16))) double tsm[];
     double* At = tsm;                                        // [ncomp][K][Np]
-    double* Bt = At + (int64_t)a.ncomp * a.K * a.Np;         // [TE][KP]
+    double* Bt = At + a.At_d;                                // [TE][KP]
     double* Jt = Bt + (int64_t)a.TE * a.KP;                  // [ndim * ndim][TE]  (grad, div)
     const int tid = threadIdx.x;
     const int Np = a.Np, K = a.K, KP = a.KP, TE = a.TE, nd = a.ndim;
@@ -123,7 +137,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
         }
     }
 
-    const int gi = tid % Np, eg = tid / Np;   // output row and element group of this thread
+    const int gi = tid % a.IW, eg = tid / a.IW;   // first row and element group of this thread
+    const bool is_grad = a.family == FE_FAMILY_GRAD;
     const bool worker = eg < a.neg;
     const int64_t nTiles = (E + TE - 1) / TE;
     for (int64_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -182,19 +197,19 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
             __syncthreads();
             // ---- out[e, i] = sum_k A_c[i, k] B[e, k]
             if (worker) {
-                double acc[3][kTiledEB];
+                double acc[kTiledRows][EB];
                 const double* ap = At + gi;
-                const double* bp = Bt + (int64_t)eg * kTiledEB * KP;
-                if (a.ncomp == 3) tiled_gemm<3>(ap, bp, K, Np, KP, acc);
-                else if (a.ncomp == 2) tiled_gemm<2>(ap, bp, K, Np, KP, acc);
-                else tiled_gemm<1>(ap, bp, K, Np, KP, acc);
+                const double* bp = Bt + (int64_t)eg * EB * KP;
+                if (!is_grad || a.ncomp == 3) tiled_gemm<3, EB>(ap, is_grad ? K * Np : a.IW, bp, K, Np, KP, acc);
+                else if (a.ncomp == 2) tiled_gemm<2, EB>(ap, K * Np, bp, K, Np, KP, acc);
+                else tiled_gemm<1, EB>(ap, K * Np, bp, K, Np, KP, acc);
                 // ---- epilogue
 #pragma unroll
-                for (int b = 0; b < kTiledEB; ++b) {
-                    const int el = eg * kTiledEB + b;
+                for (int b = 0; b < EB; ++b) {
+                    const int el = eg * EB + b;
                     if (el >= te) continue;
                     const int64_t e = e0 + el;
-                    if (a.family == FE_FAMILY_GRAD) {
+                    if (is_grad) {
                         for (int x = 0; x < nd; ++x) {
                             double v = Jt[(x * nd + 0) * TE + el] * acc[0][b];
                             if (nd > 1) v += Jt[(x * nd + 1) * TE + el] * acc[1][b];
@@ -202,7 +217,9 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                             out[((int64_t)x * E + e) * Np + gi] = v;
                         }
                     } else {
-                        out[e * Np + gi] = acc[0][b];
+#pragma unroll
+                        for (int m = 0; m < kTiledRows; ++m)
+                            if (gi + m * a.IW < Np) out[e * Np + gi + m * a.IW] = acc[m][b];
                     }
                 }
             }

@@ -109,14 +109,18 @@ int launch_tiled(fe::TiledArgs a, hipStream_t s) {
         return fail(FE_EUNSUPPORTED, "tiled kernel: operator and tile need %lld bytes of LDS (limit %lld)",
                     (long long)lds, (long long)kTiledMaxLds);
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::tiled_apply_kernel, (int)kTiledMaxLds); });
+    const int attr_rc = once.run([] {
+        const int rc = set_max_lds(fe::tiled_apply_kernel<8>, (int)kTiledMaxLds);
+        return rc != FE_OK ? rc : set_max_lds(fe::tiled_apply_kernel<4>, (int)kTiledMaxLds);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = (a.E + a.TE - 1) / a.TE;
     int64_t per_cu = kTiledMaxLds / lds;   // resident blocks per CU: LDS, and 2048 threads
     if (per_cu > 2048 / fe::kTiledThreads) per_cu = 2048 / fe::kTiledThreads;
     const int64_t cap = per_cu * device_cu_count();
-    hipLaunchKernelGGL(fe::tiled_apply_kernel, dim3((unsigned)(nTiles < cap ? nTiles : cap)), dim3(fe::kTiledThreads),
-                       (size_t)lds, s, a);
+    const dim3 grid((unsigned)(nTiles < cap ? nTiles : cap)), block(fe::kTiledThreads);
+    if (a.EB == 8) hipLaunchKernelGGL(fe::tiled_apply_kernel<8>, grid, block, (size_t)lds, s, a);
+    else hipLaunchKernelGGL(fe::tiled_apply_kernel<4>, grid, block, (size_t)lds, s, a);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
