@@ -215,20 +215,21 @@ def main() -> None:
                     traffic = rec.get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
+        e_txt = f"{E:.0e}".replace("e+0", "e").replace("e+", "e")   # 1000000 -> "1e6"
         ai = flops_step / bytes_step
         roof_gflops = min(FP64_PEAK_GFLOPS, ai * HBM_PEAK_GBS)
         line = {
-            "metric": "GFLOP/s on DG-wave p=4 grad einsum (1e6 elems per GPU, fp64); fraction of roofline in `roofline`"
-                      if args.workload == "grad" else f"GFLOP/s on DG-wave p=4 {args.workload} (1e6 elems per GPU, fp64)",
+            "metric": f"GFLOP/s on DG-wave p=4 grad einsum ({e_txt} elems per GPU, fp64); fraction of roofline in `roofline`"
+                      if args.workload == "grad" else f"GFLOP/s on DG-wave p=4 {args.workload} ({e_txt} elems per GPU, fp64)",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": {"grad": "configs[1]: grad xre,rij,ej->xei p=4 (Np=35), 1e6 elements per GPU",
-                             "div": "div xre,rij,xej->ei p=4, 1e6 elements per GPU",
-                             "facemass": "configs[3]: face-mass ef,fij,fej->ei x4 p=4, 1e6 elements per GPU",
-                             "graddiv": "configs[2]: div xre,rij,xej->ei + grad sharing J and D, p=4, 1e6 elements per GPU",
-                             "pipeline": "configs[4]: div + grad + face-mass x4, 1e6 elements per GPU"}[args.workload],
+                "workload": {"grad": f"configs[1]: grad xre,rij,ej->xei p=4 (Np=35), {e_txt} elements per GPU",
+                             "div": f"div xre,rij,xej->ei p=4, {e_txt} elements per GPU",
+                             "facemass": f"configs[3]: face-mass ef,fij,fej->ei x4 p=4, {e_txt} elements per GPU",
+                             "graddiv": f"configs[2]: div xre,rij,xej->ei + grad sharing J and D, p=4, {e_txt} elements per GPU",
+                             "pipeline": f"configs[4]: div + grad + face-mass x4, {e_txt} elements per GPU"}[args.workload],
                 "elements_per_gpu": E, "parallelism": f"element-sharded x{n}, no data-path collective",
                 "variant": args.variant, "device": q.device.name, "launches_per_step": list(op.entry_points),
             },
