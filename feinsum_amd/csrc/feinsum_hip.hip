@@ -473,6 +473,8 @@ int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp
         case FE_FAMILY_GRADDIV: return 2 * (2 * 3 * np * np + 2 * 9 * np);
         case FE_FAMILY_FACEMASS: return (int64_t)b * ((int64_t)nf * Nfp + 2 * np * nf * Nfp);
         case FE_FAMILY_DIVCOMP: return 3 * np + 2 * 3 * np * np;
+        case FE_FAMILY_GRADPLANES: return (int64_t)(b > 0 ? b : 1) * (3 * np + 2 * 3 * np * np);   // b = output planes
+        case FE_FAMILY_MATAPPLY: return (int64_t)(b > 0 ? b : 1) * (2 * np * np + np);                // with the J[e] factor
         default: return -1;
     }
 }

@@ -216,7 +216,8 @@ int fe_facemass_f64(const double* J, const double* R,
 /* Algorithmic flops per element for a family (numerator of GFLOP/s; same
  * counter as measure.py:278-331 on the opt_einsum-optimal schedule):
  * grad/div 2*3*Np*Np + 2*9*Np; face-mass b*(nf*Nfp + 2*Np*nf*Nfp);
- * div component 3*Np + 2*3*Np*Np. */
+ * div component 3*Np + 2*3*Np*Np (grad planes: the same per output plane, b = planes);
+ * element-local operator b*(2*Np*Np + Np). */
 int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf,
                              int32_t Nfp, int32_t b);
 

@@ -36,6 +36,8 @@ def test_version_and_flop_counters():
     assert _hip.flops_per_element(3, 35) == 15960           # fused grad + div
     assert _hip.flops_per_element(4, 35, 4, 15, 4) == 17040  # face-mass x4
     assert _hip.flops_per_element(5, 35) == 7455             # div component (x3 = 22365)
+    assert _hip.flops_per_element(6, 35, b=12) == 89460      # cross-product batch: 12 planes
+    assert _hip.flops_per_element(7, 35, b=4) == 9940        # e,ij,ej->ei x4
     assert _hip.flops_per_element(99, 35) == -1
 
 
