@@ -32,11 +32,6 @@
 
 namespace fe {
 
-constexpr int kNp35 = 35;
-constexpr int kTE = 16;                    // elements per MFMA sub-tile (N)
-constexpr int kTileD35 = kTE * kNp35;      // 560 doubles  (used by fe_div.h / fe_facemass.h)
-constexpr int kTileB35 = kTileD35 * 8;     // 4480 bytes
-
 constexpr int grad_row_tiles(int np) {
     int t = 1;
     while (4 * ((4 * t) / 3) < np) ++t;
