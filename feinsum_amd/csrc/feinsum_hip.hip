@@ -527,6 +527,8 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* 
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad planes: bad operator flags %d", op_flags);
     if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
         return fail(FE_EUNSUPPORTED, "grad planes: unknown variant %d", variant);
+    if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
+    if (E == 0) return FE_OK;   // empty arrays have no addresses to tell wanted planes from unwanted ones
     fe::GradFields P = {};
     int nx = -1;
     for (int k = 0; k < b; ++k) {

@@ -1,0 +1,30 @@
+"""Seeded random sweep (tools/fuzz_gpu.py) over families, shapes, layouts, field counts, element
+counts (0, 1, around the tile sizes, ragged) and kernel variants against the oracle."""
+
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_cases_all_variants():
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import fuzz_gpu
+
+    assert fuzz_gpu.run(120, seed=7) == 0
+
+
+def test_empty_batch_of_planes():
+    # E = 0: empty tensors have no addresses; the planes launch must not mistake them for unwanted planes
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd.measure import generate_host_input_arrays
+
+    expr = dg.cross_product_batch()
+    host = generate_host_input_arrays(expr, 0)
+    outs = f.evaluate(expr, 0, {k: torch.from_numpy(v).cuda() for k, v in host.items()}, wait=True)
+    assert all(tuple(o.shape) == (0, 35) for o in outs.values())

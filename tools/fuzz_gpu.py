@@ -1,0 +1,85 @@
+"""Seeded random sweep over families, shapes, layouts, field counts, element counts and kernel
+variants against the numpy oracle (test infrastructure, like tests/).
+
+    python tools/fuzz_gpu.py [n_cases] [seed]
+"""
+import random
+import sys
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import dg  # noqa: E402
+import feinsum_amd as f  # noqa: E402
+from feinsum_amd.measure import generate_host_input_arrays  # noqa: E402
+from oracle import np_oracle  # noqa: E402
+
+rng = random.Random(0)
+ORDERS3 = [(4, 3), (10, 6), (20, 10), (35, 15), (56, 21), (7, 4), (13, 5)]
+ORDERS2 = [(3, 2), (6, 3), (10, 4), (15, 5), (21, 6)]
+
+
+def build():
+    kind = rng.choice(["grad", "div", "bgrad", "bdiv", "fm", "fm_ifj", "fm_jfi", "fm_fji", "divcomp", "cross", "mass",
+                       "apply", "grad2", "div2", "lift2"])
+    Np, Nfp = rng.choice(ORDERS2 if kind.endswith("2") else ORDERS3)
+    b = rng.choice([1, 2, 3, 4, 5, 8, 9])
+    op = rng.choice(["rij", "rji"])
+    if kind == "grad":
+        return f"grad Np={Np} {op}", f.einsum(f"xre,{op},ej->xei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)), f.array("u", ("E", Np)))
+    if kind == "div":
+        return f"div Np={Np} {op}", f.einsum(f"xre,{op},xej->ei", f.array("J", (3, 3, "E")), f.array("R", (3, Np, Np)), f.array("u", (3, "E", Np)))
+    if kind == "bgrad":
+        return f"batched grad Np={Np} b={b} {op}", dg.batched_grad(b, Np, op)
+    if kind == "bdiv":
+        return f"batched div Np={Np} b={b} {op}", dg.batched_div(b, Np, op)
+    if kind.startswith("fm"):
+        fn = {"fm": dg.face_mass, "fm_ifj": dg.face_mass_ifj_fe, "fm_jfi": dg.face_mass_jfi_fe, "fm_fji": dg.face_mass_fji}[kind]
+        return f"{kind} Np={Np} Nfp={Nfp} b={b}", fn(b, Np=Np, Nfp=Nfp)
+    if kind == "divcomp":
+        return f"div components Np={Np}", dg.batched_div_components(Np)
+    if kind == "cross":
+        return f"cross product Np={Np} {op}", dg.cross_product_batch(Np, op)
+    if kind == "mass":
+        return f"mass apply Np={Np} b={b}", dg.mass_apply(b, Np, rng.choice(["ij", "ji"]))
+    if kind == "apply":
+        return f"operator apply Np={Np}", dg.operator_apply(Np, rng.choice(["ij", "ji"]))
+    if kind == "grad2":
+        return f"2D grad Np={Np} b={b}", f.batched_einsum(f"xre,{op},ej->xei", [[f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np)), f.array(f"u{k}", ("E", Np))] for k in range(b)])
+    if kind == "div2":
+        return f"2D div Np={Np} b={b}", f.batched_einsum(f"xre,{op},xej->ei", [[f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np)), f.array(f"u{k}", (2, "E", Np))] for k in range(b)])
+    return f"2D lift Np={Np} Nfp={Nfp} b={b}", f.batched_einsum("ef,fij,fej->ei", [[f.array("J", ("E", 3)), f.array("R", (3, Np, Nfp)), f.array(f"v{k}", (3, "E", Nfp))] for k in range(b)])
+
+
+def run(n_cases: int, seed: int) -> int:
+    """Number of failing (case, variant, output) triples; prints them."""
+    rng.seed(seed)
+    worst, failures = 0.0, 0
+    for case in range(n_cases):
+        name, expr = build()
+        E = rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 500, 1003, 4099, rng.randrange(1, 30000)])
+        host = generate_host_input_arrays(expr, E, np_seed=case)
+        ref = {n: np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in row]])[0]
+               for n, row in zip(expr.output_names, expr.args)}
+        dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+        for variant in ("auto", "generic", "mfma", "tiled"):
+            try:
+                outs = f.evaluate(expr, 0, dev, transform=variant, wait=True)
+            except NotImplementedError:
+                continue
+            for k in ref:
+                got = outs[k].cpu().numpy()
+                err = np_oracle.max_rel_err(got, ref[k]) if ref[k].size else 0.0
+                worst = max(worst, err)
+                if got.shape != ref[k].shape or not np.isfinite(got).all() or err > 1e-12:
+                    failures += 1
+                    print(f"FAIL case {case}: {name} E={E} variant={variant} output {k}: err {err:.3e}", flush=True)
+    print(f"{n_cases} cases, worst relative error {worst:.3e}, failures {failures}")
+    return failures
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
+
