@@ -14,6 +14,8 @@ def test_random_cases_all_variants():
     import fuzz_gpu
 
     assert fuzz_gpu.run(120, seed=7) == 0
+    assert fuzz_gpu.run_operator(30, seed=7) == 0
+    assert fuzz_gpu.run_einsum(120, seed=7) == 0
 
 
 def test_empty_batch_of_planes():

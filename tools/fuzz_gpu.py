@@ -80,6 +80,71 @@ def run(n_cases: int, seed: int) -> int:
     return failures
 
 
-if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
 
+
+
+def run_operator(n_cases: int, seed: int) -> int:
+    """div + grad (+ lift) bound as one operator: fused launches against the oracle."""
+    rng.seed(seed)
+    failures = 0
+    for case in range(n_cases):
+        Np, Nfp = rng.choice(ORDERS3[:5])
+        b = rng.choice([1, 2, 3, 4, 5])
+        E = rng.choice([1, 15, 16, 17, 47, 48, 49, 79, 80, 81, 1003, rng.randrange(1, 20000)])
+        exprs = [dg.div(Np), dg.grad(Np)] + ([rng.choice([dg.face_mass, dg.face_mass_ifj_fe])(b, Np=Np, Nfp=Nfp)]
+                                            if rng.random() < 0.7 else [])
+        hosts = [generate_host_input_arrays(e, E, np_seed=case + k) for k, e in enumerate(exprs)]
+        if rng.random() < 0.8:
+            hosts[1]["J"], hosts[1]["R"] = hosts[0]["J"], hosts[0]["R"]
+        devs = [{k: torch.from_numpy(v).cuda() for k, v in h.items()} for h in hosts]
+        if hosts[1]["J"] is hosts[0]["J"]:
+            devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+        outs = f.evaluate_operator(list(zip(exprs, devs)), 0, wait=True)
+        for e, h, o in zip(exprs, hosts, outs):
+            for name, row in zip(e.output_names, e.args):
+                ref = np_oracle.reference_outputs(e.get_subscripts(), [[h[a.name] for a in row]])[0]
+                got = o[name].cpu().numpy()
+                if not np.isfinite(got).all() or np_oracle.max_rel_err(got, ref) > 1e-12:
+                    failures += 1
+                    print(f"FAIL operator case {case}: Np={Np} b={b} E={E} {e.get_subscripts()} {name}", flush=True)
+    print(f"{n_cases} operator cases, failures {failures}")
+    return failures
+
+
+def run_einsum(n_cases: int, seed: int) -> int:
+    """Random explicit-mode einsums through the generic kernels (lane groups, pointwise stream)."""
+    rng.seed(seed)
+    failures = 0
+    for case in range(n_cases):
+        letters = "abcde"
+        dims = {c: rng.choice([1, 2, 3, 4, 7, 16, 35]) for c in letters}
+        long_idx = rng.choice(letters)
+        n_ops = rng.choice([1, 2, 3])
+        ops = ["".join(rng.sample(letters, rng.choice([1, 2, 3]))) for _ in range(n_ops)]
+        if not any(long_idx in o for o in ops):
+            ops[0] = long_idx + "".join(c for c in ops[0] if c != long_idx)[:2]
+        used = sorted(set("".join(ops)))
+        out = "".join(c for c in rng.sample(used, len(used)) if c == long_idx or rng.random() < 0.5)
+        if long_idx not in out:
+            out += long_idx
+        subs = ",".join(ops) + "->" + out
+        arrays = [f.array(f"A{k}", tuple("E" if c == long_idx else dims[c] for c in o)) for k, o in enumerate(ops)]
+        try:
+            expr = f.einsum(subs, *arrays)
+        except (ValueError, TypeError):
+            continue
+        E = rng.choice([1, 5, 64, 257, 3000])
+        host = generate_host_input_arrays(expr, E, np_seed=case)
+        ref = np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in expr.args[0]]])[0]
+        got = f.evaluate(expr, 0, {k: torch.from_numpy(v).cuda() for k, v in host.items()}, wait=True)["_fe_out"].cpu().numpy()
+        if got.shape != ref.shape or not np.isfinite(got).all() or np_oracle.max_rel_err(got, ref) > 1e-12:
+            failures += 1
+            print(f"FAIL einsum case {case}: {subs} dims={dims} E={E}", flush=True)
+    print(f"{n_cases} einsum cases, failures {failures}")
+    return failures
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    sys.exit(1 if run(n, seed) + run_operator(n // 4, seed) + run_einsum(n, seed) else 0)
