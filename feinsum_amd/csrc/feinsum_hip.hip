@@ -715,7 +715,7 @@ int fe_matapply_f64(const double* J, const double* D, const double* const* u, do
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
-    const bool mfma_ok = Np == 35 || Np == 20 || Np == 15 || Np == 10 || Np == 6 || Np == 4 || Np == 3;
+    const bool mfma_ok = Np == 56 || Np == 35 || Np == 20 || Np == 15 || Np == 10 || Np == 6 || Np == 4 || Np == 3;
     const fe::TiledArgs ta = tiled_args(FE_FAMILY_MATAPPLY, J, D, P, b, E, 1, Np, 0, 0, opT, 0, 0);
     KernelPath path;
     if (int rc = choose_path(variant, mfma_ok, tiled_fits(ta), "matapply", Np, &path)) return rc;
@@ -724,6 +724,7 @@ int fe_matapply_f64(const double* J, const double* D, const double* const* u, do
     if (path == kPathMfma) {
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements: a few KB per tile at every order
+            case 56: rc = launch_matapply<56, 1>(J, D, P, b, E, opT, s, &e_done); break;   // p = 5
             case 35: rc = launch_matapply<35, 2>(J, D, P, b, E, opT, s, &e_done); break;
             case 20: rc = launch_matapply<20, 4>(J, D, P, b, E, opT, s, &e_done); break;
             case 15: rc = launch_matapply<15, 4>(J, D, P, b, E, opT, s, &e_done); break;

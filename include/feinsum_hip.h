@@ -176,7 +176,7 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D,
  *                                                    (tuning/impls/e_ij_ej_to_ei_no_prftch.py:30-38)
  *   J == NULL:   out_k[e,i] = sum_j D[i,j] u_k[e,j]  'ij,ej->ei' (tuning/impls/ij_ej_to_ei_no_prftch.py)
  *   J [E] or NULL   D [Np][Np] ([Np(j)][Np(i)] with FE_OP_TRANSPOSED)   u_k, out_k [E][Np]
- *   u, out: HOST arrays of b device pointers.  MFMA kernels for Np in {3,4,6,10,15,20,35}. */
+ *   u, out: HOST arrays of b device pointers.  MFMA kernels for Np in {3,4,6,10,15,20,35,56}. */
 int fe_matapply_f64(const double* J, const double* D,
                     const double* const* u, double* const* out,
                     int64_t E, int32_t Np, int32_t b, int32_t op_flags,

@@ -226,12 +226,12 @@ def test_div_component_rows_that_cannot_share_stay_separate(torch_cuda):
         assert (bound.group_family == 6) == (name == "three planes"), name
 
 
-@pytest.mark.parametrize("Np", [3, 4, 6, 10, 15, 20, 35, 56])
+@pytest.mark.parametrize("Np", [3, 4, 6, 10, 15, 20, 35, 56, 84])
 @pytest.mark.parametrize("E", [15, 16, 127, 128, 129, 1003, 10007])
 def test_element_local_operator(torch_cuda, Np, E):
     # 'e,ij,ej->ei' x b (b = 4, 5, 6, 16 in the archive) and 'ij,ej->ei', plain and transposed operator:
     # the one-component instances of the div template; wave tiles of 32 .. 128 elements
-    variants = ["auto", "generic"] + (["mfma"] if Np != 56 else [])
+    variants = ["auto", "generic", "tiled"] + (["mfma"] if Np != 84 else [])
     for expr in (dg.mass_apply(4, Np), dg.mass_apply(5, Np, "ji"), dg.operator_apply(Np), dg.operator_apply(Np, "ji")):
         host = generate_host_input_arrays(expr, E, np_seed=Np + E)
         ref = _oracle(expr, host)

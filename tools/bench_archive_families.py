@@ -22,7 +22,7 @@ cases = {
     "ej,ej->ej": f.einsum("ej,ej->ej", f.array("A", ("E", Np)), f.array("B", ("E", Np))),
     "fej,fej->fej": f.einsum("fej,fej->fej", f.array("A", (4, "E", 15)), f.array("B", (4, "E", 15))),
 }
-for n in (20, 10, 4):
+for n in (56, 20, 10, 4):
     cases[f"e,ij,ej->ei x4 Np={n}"] = f.batched_einsum("e,ij,ej->ei", [[f.array("J", ("E",)), f.array("D", (n, n)),
                                                                        f.array(f"u{k}", ("E", n))] for k in range(4)])
 for name, expr in cases.items():
