@@ -131,7 +131,9 @@ enum KernelPath { kPathGeneric, kPathMfma, kPathTiled };
 int choose_path(int variant, bool mfma_ok, bool tiled_ok, const char* what, int Np, KernelPath* path) {
     if (variant == FE_VARIANT_GENERIC) { *path = kPathGeneric; return FE_OK; }
     if (variant == FE_VARIANT_TILED) {
-        if (!tiled_ok) return fail(FE_EUNSUPPORTED, "%s: the tiled kernel does not fit this shape in LDS (Np=%d)", what, Np);
+        if (!tiled_ok)
+            return fail(FE_EUNSUPPORTED, "%s: the tiled kernel does not serve this call (operator too large for LDS, or "
+                        "separate output planes; Np=%d)", what, Np);
         *path = kPathTiled;
         return FE_OK;
     }

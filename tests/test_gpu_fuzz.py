@@ -30,3 +30,59 @@ def test_empty_batch_of_planes():
     host = generate_host_input_arrays(expr, 0)
     outs = f.evaluate(expr, 0, {k: torch.from_numpy(v).cuda() for k, v in host.items()}, wait=True)
     assert all(tuple(o.shape) == (0, 35) for o in outs.values())
+
+
+@pytest.mark.parametrize("variant", ["auto", "tiled", "generic"])
+def test_kernels_write_only_their_outputs(variant):
+    """Outputs placed between sentinel guard bands: nothing outside the output arrays is written
+    (ragged element counts, every family, batched and fused launches)."""
+    import numpy as np
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd.measure import generate_host_input_arrays
+
+    guard = 4096
+    exprs = [dg.grad(), dg.div(), dg.face_mass(4), dg.face_mass_ifj_fe(3), dg.batched_grad(3), dg.batched_div(2),
+             dg.batched_div_components(), dg.cross_product_batch(), dg.mass_apply(4), dg.operator_apply(),
+             dg.grad(20), dg.div(10), dg.face_mass(4, Np=4, Nfp=3), dg.grad(56), dg.face_mass(4, Np=56, Nfp=21)]
+    for E in (17, 1003, 4111):
+        for expr in exprs:
+            host = generate_host_input_arrays(expr, E, np_seed=E)
+            dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+            shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+            n = int(np.prod(shape))
+            bufs, outs = [], {}
+            for name in expr.output_names:
+                buf = torch.full((n + 2 * guard,), -7.25, dtype=torch.float64, device="cuda")
+                bufs.append(buf)
+                outs[name] = buf[guard:guard + n].view(shape)
+            try:
+                f.evaluate(expr, 0, dev, out_dict=outs, transform=variant, wait=True)
+            except NotImplementedError:      # e.g. "tiled" for the planes launch
+                continue
+            for buf in bufs:
+                assert bool((buf[:guard] == -7.25).all()) and bool((buf[guard + n:] == -7.25).all()), (expr.get_subscripts(), E)
+                assert bool(torch.isfinite(buf[guard:guard + n]).all()) and not bool((buf[guard:guard + n] == -7.25).any())
+    # the fused operator launches too
+    E = 1003
+    stages = []
+    for k, expr in enumerate((dg.div(), dg.grad(), dg.face_mass(4))):
+        host = generate_host_input_arrays(expr, E, np_seed=k)
+        stages.append((expr, {n: torch.from_numpy(v).cuda() for n, v in host.items()}))
+    stages[1][1]["J"], stages[1][1]["R"] = stages[0][1]["J"], stages[0][1]["R"]
+    out_dicts, bufs = [], []
+    for expr, _ in stages:
+        shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+        n = int(np.prod(shape))
+        od = {}
+        for name in expr.output_names:
+            buf = torch.full((n + 2 * guard,), -7.25, dtype=torch.float64, device="cuda")
+            bufs.append((buf, n))
+            od[name] = buf[guard:guard + n].view(shape)
+        out_dicts.append(od)
+    f.evaluate_operator(stages, 0, out_dicts=out_dicts, transform=variant, wait=True)
+    for buf, n in bufs:
+        assert bool((buf[:guard] == -7.25).all()) and bool((buf[guard + n:] == -7.25).all())
+        assert not bool((buf[guard:guard + n] == -7.25).any())
