@@ -27,6 +27,12 @@
 // MODE 2 ('e,ij,ej->ei': out[e,i] = J[e] sum_j D[i,j] u[e,j], tuning/impls/
 // e_ij_ej_to_ei_no_prftch.py:30-38) and MODE 3 ('ij,ej->ei', tuning/impls/ij_ej_to_ei_no_prftch.py)
 // are the same with ONE operator component (NC = 1): B fragment = J[e] u[e,j], or u[e,j] itself.
+// MODE 4 is grad 'xre,rij,ej->xei' BY COMPONENTS: the ND products D_r u keep separate accumulators
+// (same B fragment u for every r) and the epilogue contracts them with J[x, r, e], which is
+// lane-local because every r has the same (row, element) accumulator layout.  It costs ND
+// accumulator sets, so it is the grad kernel of the small 2-D operators (ND = 2, Np <= 21), where
+// the row-permuted kernel of fe_grad.h (written for ND = 3) does not apply.  ND = 2 also turns
+// MODE 0 into the div of triangles.
 // Data movement as in fe_grad.h; a wave tile is 16 M elements.  The three u planes of a tile
 // leave no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a tile are
 // computed up front, which frees the u buffer, and the next tile's loads are issued before
@@ -36,12 +42,14 @@
 
 namespace fe {
 
-template <int NP, int M, int MODE = 0>
+template <int NP, int M, int MODE = 0, int ND = 3>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
-    static constexpr int NPLANES = MODE ? 1 : 3;        // u planes per tile
-    static constexpr int NC = MODE >= 2 ? 1 : 3;        // operator components r
-    static constexpr int NJ = MODE == 0 ? 9 : MODE == 1 ? 3 : MODE == 2 ? 1 : 0;   // J values per element
+    static constexpr int NPLANES = MODE == 0 ? ND : 1;  // u planes per tile
+    static constexpr int NC = (MODE == 0 || MODE == 4) ? ND : MODE == 1 ? 3 : 1;   // operator components r
+    static constexpr int NJ = (MODE == 0 || MODE == 4) ? ND * ND : MODE == 1 ? 3 : MODE == 2 ? 1 : 0;   // J values per element
+    static constexpr int NBF = MODE == 4 ? 1 : NC;      // distinct B fragments per k-quad
+    static constexpr int NOUT = MODE == 4 ? ND : 1;     // output planes
     static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = NC KSJ, ordered (jq, r)
     static constexpr int BT = NP / 16;                  // 16-row tiles
     static constexpr int NR = NP - 16 * BT;             // rows left for the 4x4x4 groups
@@ -51,7 +59,7 @@ struct DivGeom {
     static constexpr int P_CHUNKS = PLANE_D / 2, P_INSTR = (P_CHUNKS + 63) / 64;
     static constexpr int J_ROW_CHUNKS = TEL / 2, J_CHUNKS = NJ * J_ROW_CHUNKS, J_INSTR = (J_CHUNKS + 63) / 64;
     static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
-    static constexpr int LOADS = NPLANES * P_INSTR + J_INSTR, STORES = M * SUB_INSTR;
+    static constexpr int LOADS = NPLANES * P_INSTR + J_INSTR, STORES = NOUT * M * SUB_INSTR;
     struct WaveLds {
         double u[NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
         double o[SUB_D];              // output transposition buffer (one 16-element sub-tile)
@@ -67,11 +75,11 @@ struct DivGeom {
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int NP, int M, int kDbg = 0, int MODE = 0>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
-    using G = DivGeom<NP, M, MODE>;
+    using G = DivGeom<NP, M, MODE, ND>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -115,7 +123,9 @@ __device__ __forceinline__ void div3d_mfma_body(
         for (int k = 0; k < nb; ++k) {
             const double* uk = field_in(P, k);
             double* ok = field_out(P, k);
-            if (MODE == 0) div3d_item(J, D, uk, ok, E, NP, e, i, opT);
+            if (MODE == 0 && ND == 3) div3d_item(J, D, uk, ok, E, NP, e, i, opT);
+            else if (MODE == 0) div_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
+            else if (MODE == 4) grad_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
             else if (MODE == 1) divcomp3d_item(J, D, uk, ok, E, NP, e, i, opT, jes);
             else matapply_item(MODE == 2 ? J : nullptr, D, uk, ok, NP, e, i, opT);
         }
@@ -167,28 +177,39 @@ __device__ __forceinline__ void div3d_mfma_body(
         first = false;
 
         // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
-        double bfrag[M][G::KSJ][NC];
+        double bfrag[M][G::KSJ][G::NBF];
+        double jkeep[MODE == 4 ? M : 1][MODE == 4 ? ND * ND : 1];   // MODE 4: J for the epilogue
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             double jac[G::NJ > 0 ? G::NJ : 1];
 #pragma unroll
-            for (int k = 0; k < G::NJ; ++k)   // jac[x*3 + r]  (MODE 1: jac[s]; MODE 2: jac[0] = J[e])
+            for (int k = 0; k < G::NJ; ++k)   // jac[x*ND + r]  (MODE 1: jac[s]; MODE 2: jac[0] = J[e])
                 jac[k] = (MODE == 1 && jes) ? L->j[(16 * m + n) * 3 + k] : L->j[k * G::TEL + 16 * m + n];
             if (G::NJ == 0) jac[0] = 1.0;
+            if (MODE == 4) {
+#pragma unroll
+                for (int k = 0; k < ND * ND; ++k) jkeep[m][k] = jac[k];
+            }
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
                 const int j = 4 * jq + g;
                 const int jc = j < NP ? j : 0;
-                double u0 = L->u[0][(16 * m + n) * NP + jc];
-                double u1 = L->u[MODE ? 0 : 1][(16 * m + n) * NP + jc];
-                double u2 = L->u[MODE ? 0 : 2][(16 * m + n) * NP + jc];
-                if (j >= NP) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
+                double ux[G::NPLANES];
 #pragma unroll
-                for (int r = 0; r < NC; ++r)
-                    bfrag[m][jq][r] = MODE == 3 ? u0
-                                    : MODE      ? jac[r] * u0
-                                                : jac[0 * 3 + r] * u0 + jac[(MODE ? 0 : 1) * 3 + r] * u1 +
-                                                      jac[(MODE ? 0 : 2) * 3 + r] * u2;
+                for (int x = 0; x < G::NPLANES; ++x) ux[x] = j < NP ? L->u[x][(16 * m + n) * NP + jc] : 0.0;
+#pragma unroll
+                for (int r = 0; r < G::NBF; ++r) {
+                    if (MODE == 3 || MODE == 4) {
+                        bfrag[m][jq][r] = ux[0];
+                    } else if (MODE) {
+                        bfrag[m][jq][r] = jac[r] * ux[0];
+                    } else {
+                        double v = jac[r] * ux[0];
+#pragma unroll
+                        for (int x = 1; x < ND; ++x) v += jac[x * ND + r] * ux[x];
+                        bfrag[m][jq][r] = v;
+                    }
+                }
             }
         }
         // the u / J tiles are now in registers: hand the buffers back to the DMA engine
@@ -197,8 +218,76 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
-                for (int r = 0; r < NC; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
+                for (int r = 0; r < G::NBF; ++r) asm volatile("" : "+v"(bfrag[m][jq][r]));
+        if (MODE == 4) {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int k = 0; k < ND * ND; ++k) asm volatile("" : "+v"(jkeep[m][k]));
+        }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
+
+        if (MODE == 4) {   // grad by components: separate accumulators per r, J contraction in the epilogue
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                v4d acc[NC][G::BT > 0 ? G::BT : 1];
+                double accs[NC][G::NS > 0 ? G::NS : 1];
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t) acc[r][t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q) accs[r][q] = 0.0;
+                }
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                    for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                        for (int t = 0; t < G::BT; ++t)
+                            acc[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[m][jq][0], acc[r][t], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < G::NS; ++q)
+                            accs[r][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16],
+                                                                            bfrag[m][jq][0], accs[r][q], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int x = 0; x < ND; ++x) {
+                    double* ob = L->o;
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            double v = jkeep[m][x * ND] * acc[0][t][qq];
+#pragma unroll
+                            for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * acc[r][t][qq];
+                            ob[n * NP + 16 * t + g + 4 * qq] = v;
+                        }
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q) {
+                        const int i = 16 * G::BT + 4 * q + g;
+                        double v = jkeep[m][x * ND] * accs[0][q];
+#pragma unroll
+                        for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * accs[r][q];
+                        if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = v;
+                    }
+                    wave_lds_fence();
+                    double* op = out + ((int64_t)x * E + e0 + 16 * m) * NP;
+#pragma unroll
+                    for (int c = 0; c < G::SUB_INSTR; ++c) {
+                        const int qc = c * 64 + lane;
+                        if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
+                            const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                            __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
+                        }
+                    }
+                    wave_lds_fence();
+                }
+            }
+            fk = nk;
+            tile = nt;
+            continue;
+        }
 
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -264,11 +353,11 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
 }
 
-template <int NP, int M, int kDbg = 0, int MODE = 0>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3>
 __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes) {
-    div3d_mfma_body<NP, M, kDbg, MODE>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
+    div3d_mfma_body<NP, M, kDbg, MODE, ND>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

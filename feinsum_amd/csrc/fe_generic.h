@@ -41,6 +41,36 @@ __global__ __launch_bounds__(256) void div3d_generic_kernel(
     div3d_item(J, D, u, out, E, Np, e_begin + idx / Np, (int)(idx % Np), opT);
 }
 
+// grad / div of ND-dimensional elements (ND = 2: triangles), entry (e, i): J [ND][ND][E], D [ND][Np][Np]
+__device__ __forceinline__ void grad_nd_item(const double* __restrict__ J, const double* __restrict__ D,
+                                             const double* __restrict__ u, double* __restrict__ out, int64_t E,
+                                             int Np, int nd, int64_t e, int i, int opT) {
+    double t[3] = {0.0, 0.0, 0.0};
+    const double* ue = u + e * Np;
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+    for (int j = 0; j < Np; ++j)
+        for (int r = 0; r < nd; ++r) t[r] += D[(int64_t)r * Np * Np + (int64_t)i * si + j * sj] * ue[j];
+    for (int x = 0; x < nd; ++x) {
+        double v = 0.0;
+        for (int r = 0; r < nd; ++r) v += J[(int64_t)(x * nd + r) * E + e] * t[r];
+        out[((int64_t)x * E + e) * Np + i] = v;
+    }
+}
+
+__device__ __forceinline__ void div_nd_item(const double* __restrict__ J, const double* __restrict__ D,
+                                            const double* __restrict__ u, double* __restrict__ out, int64_t E,
+                                            int Np, int nd, int64_t e, int i, int opT) {
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+    double acc = 0.0;
+    for (int j = 0; j < Np; ++j)
+        for (int r = 0; r < nd; ++r) {
+            double ju = 0.0;
+            for (int x = 0; x < nd; ++x) ju += J[(int64_t)(x * nd + r) * E + e] * u[((int64_t)x * E + e) * Np + j];
+            acc += D[(int64_t)r * Np * Np + (int64_t)i * si + j * sj] * ju;
+        }
+    out[e * Np + i] = acc;
+}
+
 // div component: out[e,i] = sum_{s,j} J[s,e] D[s,i,j] u[e,j]   ('se,sij,ej->ei')
 __device__ __forceinline__ void divcomp3d_item(const double* __restrict__ J, const double* __restrict__ D,
                                                const double* __restrict__ u, double* __restrict__ out,

@@ -421,6 +421,34 @@ int launch_waveop(fe::WaveOpArgs a, const fe::GradFields& Pg, const fe::FieldPtr
     }
 }
 
+// triangles (ND = 2): grad by components (MODE 4) and div (MODE 0) instances of the div template
+template <int NP, int M, int MODE>
+int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
+               hipStream_t s, bool* launched) {
+    using G = fe::DivGeom<NP, M, MODE, 2>;
+    const int64_t nTiles = E / G::TEL;
+    *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
+    if (nTiles == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
+                       G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+    return FE_OK;
+}
+
+template <int MODE>
+int launch_nd2_np(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int Np, int opT,
+                  hipStream_t s, bool* launched) {
+    switch (Np) {   // triangles p = 1..5; a wave tile of 16 M elements moves a few KB
+        case 21: return launch_nd2<21, (MODE == 0 ? 2 : 3), MODE>(J, D, P, nb, E, opT, s, launched);
+        case 15: return launch_nd2<15, 4, MODE>(J, D, P, nb, E, opT, s, launched);
+        case 10: return launch_nd2<10, 6, MODE>(J, D, P, nb, E, opT, s, launched);
+        case 6: return launch_nd2<6, 8, MODE>(J, D, P, nb, E, opT, s, launched);
+        default: return launch_nd2<3, 8, MODE>(J, D, P, nb, E, opT, s, launched);
+    }
+}
+
 struct FmChoice { int max_group, tel; };
 // (Np, Nfp) pairs of tetrahedral orders p = 1..4 with nf = 4
 inline bool fm_mfma_geometry(int Np, int nf, int Nfp, FmChoice* c) {
@@ -622,7 +650,7 @@ int fe_div3d_batched_f64(const double* J, const double* D, const double* const* 
 }
 
 // grad / div of ndim-dimensional elements: ndim = 3 is the 3d entry point; ndim = 2 (triangles)
-// runs on the tiled kernel.
+// runs on the MFMA instances above for p = 1..5, else on the tiled kernel.
 static int nd_launch(int family, const char* what, const double* J, const double* D, const double* const* u,
                      double* const* out, int64_t E, int32_t ndim, int32_t Np, int32_t b, int32_t op_flags,
                      int32_t variant, void* stream) {
@@ -630,8 +658,11 @@ static int nd_launch(int family, const char* what, const double* J, const double
     if (!u || !out) return fail(FE_EINVAL, "%s: null pointer table", what);
     if (b < 1) return fail(FE_EINVAL, "%s: b=%d, need at least one field", what, b);
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "%s: bad operator flags %d", what, op_flags);
-    if (variant != FE_VARIANT_AUTO && variant != FE_VARIANT_TILED)
-        return fail(FE_EUNSUPPORTED, "%s: only the tiled kernel serves ndim = 2 (variant %d)", what, variant);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED || variant == FE_VARIANT_GENERIC)
+        return fail(FE_EUNSUPPORTED, "%s: ndim = 2 has the MFMA and the tiled kernels (variant %d)", what, variant);
+    const bool mfma_ok = Np == 3 || Np == 6 || Np == 10 || Np == 15 || Np == 21;
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {
         const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
         fe::FieldPtrs P = {};
@@ -641,10 +672,21 @@ static int nd_launch(int family, const char* what, const double* J, const double
             P.out[k] = out[k0 + k];
         }
         if (E == 0) continue;
-        if (int rc = launch_tiled(tiled_args(family, J, D, P, nb, E, ndim, Np, 0, 0, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0,
-                                             0, 0), static_cast<hipStream_t>(stream)))
-            return rc;
+        const fe::TiledArgs ta = tiled_args(family, J, D, P, nb, E, ndim, Np, 0, 0, opT, 0, 0);
+        KernelPath path;
+        if (int rc = choose_path(variant, mfma_ok, tiled_fits(ta), what, Np, &path)) return rc;
+        bool launched = false;
+        if (path == kPathMfma) {
+            const int rc = family == FE_FAMILY_GRAD ? launch_nd2_np<4>(J, D, P, nb, E, Np, opT, s, &launched)
+                                                    : launch_nd2_np<0>(J, D, P, nb, E, Np, opT, s, &launched);
+            if (rc != FE_OK) return rc;
+        }
+        if (!launched) {   // no MFMA geometry, or fewer elements than one wave tile
+            if (!tiled_fits(ta)) return fail(FE_EUNSUPPORTED, "%s: no kernel for ndim = 2, Np = %d", what, Np);
+            if (int rc = launch_tiled(ta, s)) return rc;
+        }
     }
+    FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
 

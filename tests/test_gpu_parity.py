@@ -315,13 +315,14 @@ def test_generic_einsum_reductions_and_pointwise(torch_cuda, E):
     _assert_close({k: v.cpu().numpy() for k, v in out.items()}, _oracle(expr, host))
 
 
-@pytest.mark.parametrize("Np,Nfp", [(3, 2), (6, 3), (10, 4), (15, 5)])
-def test_two_dimensional_operators(torch_cuda, Np, Nfp):
-    # triangles (ndim = 2, three faces): grad / div on the tiled kernel (fe_grad_f64 / fe_div_f64),
+@pytest.mark.parametrize("Np,Nfp", [(3, 2), (6, 3), (10, 4), (15, 5), (21, 6), (28, 7)])
+@pytest.mark.parametrize("E", [5, 127, 128, 129, 1003, 6007])
+def test_two_dimensional_operators(torch_cuda, Np, Nfp, E):
+    # triangles (ndim = 2, three faces): grad / div through fe_grad_f64 / fe_div_f64 -- MFMA instances
+    # of the div template for p = 1..5 (grad by components), the tiled kernel otherwise (p = 6) -- and
     # the lift on the face-mass entry point with nf = 3
     import feinsum_amd as f2
 
-    E = 1003
     grad2 = f2.einsum("xre,rij,ej->xei", f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)), f2.array("u", ("E", Np)))
     div2 = f2.einsum("xre,rij,xej->ei", f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)),
                      f2.array("u", (2, "E", Np)))
@@ -335,6 +336,8 @@ def test_two_dimensional_operators(torch_cuda, Np, Nfp):
         ref = _oracle(expr, host)
         _assert_close(_run(torch_cuda, expr, host), ref)
         _assert_close(_run(torch_cuda, expr, host, transform="tiled"), ref)
+        if Np <= 21 and expr is not lift2:
+            _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
 
 
 @pytest.mark.parametrize("Np,Nfp", [(4, 3), (20, 10), (35, 15), (56, 21)])
