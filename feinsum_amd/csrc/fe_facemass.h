@@ -23,28 +23,29 @@
 
 namespace fe {
 
-constexpr int kFmNf = 4;
+constexpr int kFmNf = 4;   // faces of a tetrahedron (the default NF); triangles: NF = 3
 
-template <int NP, int NFP, int M>
+template <int NP, int NFP, int M, int NF = kFmNf>
 struct FmGeom {
     static constexpr int TEL = 16 * M;
-    static constexpr int KS = NFP;                      // K = 4 NFP = NFP k-steps of 4
+    static constexpr int K = NF * NFP;
+    static constexpr int KS = (K + 3) / 4;              // k-steps of 4 (NF = 4: exactly NFP of them)
     static constexpr int BT = NP / 16, NR = NP - 16 * BT, NS = (NR + 3) / 4;
     static constexpr int SLAB_D = TEL * NFP;            // doubles per face slab of a unit
-    static constexpr int UNIT_D = kFmNf * SLAB_D;
+    static constexpr int UNIT_D = NF * SLAB_D;
     static constexpr int SUB_D = 16 * NP;
     static constexpr int SLAB_CHUNKS = SLAB_D / 2, SLAB_INSTR = (SLAB_CHUNKS + 63) / 64;
-    static constexpr int J_CHUNKS = 2 * TEL, J_INSTR = (J_CHUNKS + 63) / 64;   // 4 TEL doubles
+    static constexpr int J_CHUNKS = NF * TEL / 2, J_INSTR = (J_CHUNKS + 63) / 64;   // NF TEL doubles
     static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
-    static constexpr int UNIT_LOADS = kFmNf * SLAB_INSTR;   // + J_INSTR at a tile start
+    static constexpr int UNIT_LOADS = NF * SLAB_INSTR;   // + J_INSTR at a tile start
     static constexpr int UNIT_STORES = M * SUB_INSTR;
     struct WaveLds {
         double v[2][UNIT_D];     // ring of field slabs: v[slot][f][e][j]
         double o[SUB_D];         // output transposition buffer (one 16-element sub-tile)
-        double j[kFmNf * TEL];   // J tile, [e][f] or [f][e] as in global memory
+        double j[NF * TEL];      // J tile, [e][f] or [f][e] as in global memory
     };
     static constexpr int WAVES = 4;
-    static constexpr int OP_D = kFmNf * NP * NFP;
+    static constexpr int OP_D = NF * NP * NFP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
     static constexpr int LDS_BYTES = WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8;
     static_assert((TEL * NFP) % 2 == 0, "slabs are moved in 16-byte chunks");
@@ -53,16 +54,16 @@ struct FmGeom {
 };
 
 // UNIT_LOADS x 16-byte LDS-DMA for the field slabs (+ J_INSTR for J at a tile start).
-template <int NP, int NFP, int M, bool kWithJ>
+template <int NP, int NFP, int M, bool kWithJ, int NF = kFmNf>
 __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J,
                                                     const double* __restrict__ vk, int64_t E,
                                                     int64_t tile, int lane, unsigned lds_v,
                                                     unsigned lds_j, int jfe) {
-    using G = FmGeom<NP, NFP, M>;
+    using G = FmGeom<NP, NFP, M, NF>;
     const int64_t e0 = tile * G::TEL;
     const char* vb = reinterpret_cast<const char*>(vk) + e0 * (NFP * 8) + lane * 16;
 #pragma unroll
-    for (int f = 0; f < kFmNf; ++f) {
+    for (int f = 0; f < NF; ++f) {
         const char* vf = vb + (int64_t)f * E * (NFP * 8);
 #pragma unroll
         for (int c = 0; c < G::SLAB_INSTR; ++c)
@@ -76,18 +77,18 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
             const int q = c * 64 + lane;                       // 16-byte chunk of the J tile
             const int row = q / (G::TEL / 2), col = q - row * (G::TEL / 2);   // "fe": 4 rows of TEL doubles
             const char* src = jfe ? jb + ((int64_t)row * E + e0) * 8 + col * 16
-                                  : jb + e0 * (kFmNf * 8) + q * 16;
+                                  : jb + e0 * (NF * 8) + q * 16;
             if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     }
 }
 
 // bid / nblk: see grad3d_mfma_body.
-template <int NP, int NFP, int M, int NB>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf>
 __device__ __forceinline__ void facemass_mfma_body(
     const double* __restrict__ J, const double* __restrict__ R, const FieldPtrs& P, int64_t E,
     int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
-    using G = FmGeom<NP, NFP, M>;
+    using G = FmGeom<NP, NFP, M, NF>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,25 +109,28 @@ __device__ __forceinline__ void facemass_mfma_body(
         __syncthreads();
         // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i] -> strides of f, i, j
         const int sF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
-        const int sI = rlayout == 0 ? NFP : rlayout == 1 ? kFmNf * NFP : 1;
-        const int sJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : kFmNf * NP;
+        const int sI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
+        const int sJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : NF * NP;
         auto ridx = [&](int f, int i, int j) { return f * sF + i * sI + j * sJ; };
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            const int k = 4 * ks + g;
+            const int kk = 4 * ks + g;
+            const bool kok = kk < G::K;            // NF NFP need not be a multiple of 4: padded k-steps
+            const int k = kok ? kk : 0;            // read a valid (finite) B value, multiply it by A = 0
             const int f = k / NFP, j = k - f * NFP;
             voff[ks] = f * G::SLAB_D + n * NFP + j;
-            joff[ks] = jfe ? f * G::TEL + n : n * kFmNf + f;
+            joff[ks] = jfe ? f * G::TEL + n : n * NF + f;
 #pragma unroll
             for (int t = 0; t < G::BT; ++t) {
                 const int i = 16 * t + n;
-                abig[t][ks] = rl[ridx(f, i, j)];
+                const double a = rl[ridx(f, i, j)];
+                abig[t][ks] = kok ? a : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) {
                 const int i3 = 16 * G::BT + 4 * q + (n & 3), i3c = i3 < NP ? i3 : 0;
                 const double a3 = rl[ridx(f, i3c, j)];
-                asmall[q][ks] = (i3 < NP) ? a3 : 0.0;
+                asmall[q][ks] = (i3 < NP && kok) ? a3 : 0.0;
             }
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
@@ -137,19 +141,19 @@ __device__ __forceinline__ void facemass_mfma_body(
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     const int64_t first = (int64_t)bid * G::WAVES + wave;
     {
-        const int64_t jEs = jfe ? 1 : kFmNf, jFs = jfe ? E : 1;
+        const int64_t jEs = jfe ? 1 : NF, jFs = jfe ? E : 1;
         const int rF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
-        const int rI = rlayout == 0 ? NFP : rlayout == 1 ? kFmNf * NFP : 1;
-        const int rJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : kFmNf * NP;
+        const int rI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
+        const int rJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : NF * NP;
         remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
-            facemass_item<NB>(J, R, P, E, NP, kFmNf, NFP, jEs, jFs, rF, rI, rJ, e, i);
+            facemass_item<NB>(J, R, P, E, NP, NF, NFP, jEs, jFs, rF, rI, rJ, e, i);
         });
     }
     if (first >= tEnd) return;
 
     // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
-    fm_issue_unit_loads<NP, NFP, M, false>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, true, NF>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, false, NF>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
 
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
@@ -176,7 +180,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 for (int m = 0; m < M; ++m)
 #pragma unroll
                     for (int ks = 0; ks < G::KS; ++ks)
-                        jv[m][ks] = L->j[joff[ks] + (jfe ? 16 * m : 16 * m * kFmNf)];
+                        jv[m][ks] = L->j[joff[ks] + (jfe ? 16 * m : 16 * m * NF)];
             }
             const double* vs = L->v[slot];
             double bfrag[M][G::KS];
@@ -198,10 +202,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 const int64_t tile2 = tile + stride * ((k + 2) / NB);
                 if (tile2 < tEnd) {
                     if (k2 == 0)
-                        fm_issue_unit_loads<NP, NFP, M, true>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, true, NF>(J, P.v[k2], E, tile2, lane,
                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                     else
-                        fm_issue_unit_loads<NP, NFP, M, false>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, false, NF>(J, P.v[k2], E, tile2, lane,
                                                                lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                 }
             }
@@ -254,11 +258,11 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
 }
 
-template <int NP, int NFP, int M, int NB>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf>
 __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
     int64_t nTiles, int jfe, int rlayout) {
-    facemass_mfma_body<NP, NFP, M, NB>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
+    facemass_mfma_body<NP, NFP, M, NB, NF>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

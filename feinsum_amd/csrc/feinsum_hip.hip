@@ -276,30 +276,31 @@ int launch_matapply(const double* J, const double* D, const fe::FieldPtrs& P, in
              : launch_matapply_mode<NP, M, 3>(J, D, P, nb, E, opT, s, e_done);
 }
 
-template <int NP, int NFP, int M, int NB>
+template <int NP, int NFP, int M, int NB, int NF = fe::kFmNf>
 int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
-    using G = fe::FmGeom<NP, NFP, M>;
+    using G = fe::FmGeom<NP, NFP, M, NF>;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB>, G::LDS_BYTES); });
+    const int attr_rc =
+        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
     const unsigned grid = persistent_grid(nTiles, G::WAVES);
-    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, R,
+    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, R,
                        P, E, nTiles, jfe, rifj);
     return FE_OK;
 }
 
 // One MFMA launch for a group of nb fields (2 <= nb <= kMaxGroup of the geometry).
-template <int NP, int NFP, int M>
+template <int NP, int NFP, int M, int NF = fe::kFmNf>
 int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, int64_t E, int64_t nTiles,
               int jfe, int rifj, hipStream_t s) {
     switch (nb) {
-        case 2: return launch_fm_nb<NP, NFP, M, 2>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 3: return launch_fm_nb<NP, NFP, M, 3>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 4: return launch_fm_nb<NP, NFP, M, 4>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 2: return launch_fm_nb<NP, NFP, M, 2, NF>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 3: return launch_fm_nb<NP, NFP, M, 3, NF>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 4: return launch_fm_nb<NP, NFP, M, 4, NF>(J, R, P, E, nTiles, jfe, rifj, s);
         default: break;
     }
-    if constexpr (NP == 35) {   // p = 4, the headline order: groups of up to 8 fields
+    if constexpr (NP == 35 && NF == fe::kFmNf) {   // p = 4, the headline order: groups of up to 8 fields
         switch (nb) {
             case 5: return launch_fm_nb<NP, NFP, M, 5>(J, R, P, E, nTiles, jfe, rifj, s);
             case 6: return launch_fm_nb<NP, NFP, M, 6>(J, R, P, E, nTiles, jfe, rifj, s);
@@ -452,6 +453,14 @@ int launch_nd2_np(const double* J, const double* D, const fe::FieldPtrs& P, int 
 struct FmChoice { int max_group, tel; };
 // (Np, Nfp) pairs of tetrahedral orders p = 1..4 with nf = 4
 inline bool fm_mfma_geometry(int Np, int nf, int Nfp, FmChoice* c) {
+    if (nf == 3) {   // triangles p = 1..5
+        if (Np == 21 && Nfp == 6) { *c = {4, 48}; return true; }
+        if (Np == 15 && Nfp == 5) { *c = {4, 64}; return true; }
+        if (Np == 10 && Nfp == 4) { *c = {4, 80}; return true; }
+        if (Np == 6 && Nfp == 3) { *c = {4, 96}; return true; }
+        if (Np == 3 && Nfp == 2) { *c = {4, 128}; return true; }
+        return false;
+    }
     if (nf != fe::kFmNf) return false;
     if (Np == 35 && Nfp == 15) { *c = {8, 16}; return true; }
     if (Np == 20 && Nfp == 10) { *c = {4, 16}; return true; }
@@ -859,8 +868,8 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
         // below ~10 rows the tiled kernel has too few busy lanes to beat the plain one (measured:
         // triangles p = 2, Np = 6: 1.4 vs 2.2 TFLOP/s; p = 4, Np = 15: 3.1 vs 2.6)
         const bool tiled_ok = tiled_fits(probe) && (variant == FE_VARIANT_TILED || Np >= 10);
-        if (int rc = choose_path(variant, mfma_ok, tiled_ok, "face-mass (MFMA: nf = 4, tetrahedral p = 1..4, b >= 2)", Np,
-                                 &path))
+        if (int rc = choose_path(variant, mfma_ok, tiled_ok,
+                                 "face-mass (MFMA: tetrahedra p = 1..4 or triangles p = 1..5, b >= 2)", Np, &path))
             return rc;
     }
     if (path == kPathTiled) {   // groups of up to kMaxFields fields share the staged operator
@@ -892,11 +901,21 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
         }
         if (nTiles > 0) {
             int rc = FE_OK;
-            switch (Np) {   // wave tile = 16 M elements
-                case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                case 20: rc = launch_fm<20, 10, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                case 10: rc = launch_fm<10, 6, 2>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                default: rc = launch_fm<4, 3, 4>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+            if (nf == 3) {
+                switch (Np) {   // triangles; wave tile = 16 M elements
+                    case 21: rc = launch_fm<21, 6, 3, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 15: rc = launch_fm<15, 5, 4, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 10: rc = launch_fm<10, 4, 5, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 6: rc = launch_fm<6, 3, 6, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    default: rc = launch_fm<3, 2, 8, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                }
+            } else {
+                switch (Np) {   // tetrahedra
+                    case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 20: rc = launch_fm<20, 10, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 10: rc = launch_fm<10, 6, 2>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    default: rc = launch_fm<4, 3, 4>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                }
             }
             if (rc != FE_OK) return rc;
         }
@@ -924,7 +943,8 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
                     const double* const* f, double* const* lift, int64_t E, int32_t Np, int32_t nf,
                     int32_t Nfp, int32_t b, int32_t fm_layout_flags, int32_t variant, void* stream) {
     FmChoice geo{0, 16};
-    const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
+    const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && nf == fe::kFmNf &&
+                       fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
                        b <= 4 && f && lift && E > 0 && !(fm_layout_flags & ~7);
     if (!fused) {   // three launches (argument checks included)
         if (int rc = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc;

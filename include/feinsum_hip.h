@@ -145,8 +145,9 @@ int fe_div3d_batched_f64(const double* J, const double* D,
  *   J [ndim][ndim][E]   D [ndim][Np][Np]   grad: u_k [E][Np] -> out_k [ndim][E][Np]
  *                                           div:  u_k [ndim][E][Np] -> out_k [E][Np]
  * ndim == 3 is fe_grad3d_batched_f64 / fe_div3d_batched_f64; ndim == 2 (triangles: the same
- * transforms with ndim = 2, tuning/impls/xre_rij_ej_to_xei.py:20-22 `ndim = e.shape[0]`) runs on
- * the LDS-tiled kernel (FE_VARIANT_AUTO / FE_VARIANT_TILED). */
+ * transforms with ndim = 2, tuning/impls/xre_rij_ej_to_xei.py:20-22 `ndim = e.shape[0]`) has MFMA
+ * kernels for Np in {3, 6, 10, 15, 21} and the LDS-tiled kernel for any other Np
+ * (FE_VARIANT_GENERIC is not available for ndim == 2). */
 int fe_grad_f64(const double* J, const double* D,
                 const double* const* u, double* const* out,
                 int64_t E, int32_t ndim, int32_t Np, int32_t b, int32_t op_flags,

@@ -336,8 +336,14 @@ def test_two_dimensional_operators(torch_cuda, Np, Nfp, E):
         ref = _oracle(expr, host)
         _assert_close(_run(torch_cuda, expr, host), ref)
         _assert_close(_run(torch_cuda, expr, host, transform="tiled"), ref)
-        if Np <= 21 and expr is not lift2:
+        if Np <= 21:
             _assert_close(_run(torch_cuda, expr, host, transform="mfma"), ref)
+    # the lift in the 'ifj,fe' spelling and with other field counts
+    for b in (2, 5):
+        lift = f2.batched_einsum("ifj,fe,fej->ei", [[f2.array("L", (Np, 3, Nfp)), f2.array("J", (3, "E")),
+                                                     f2.array(f"v{k}", (3, "E", Nfp))] for k in range(b)])
+        host = generate_host_input_arrays(lift, E, np_seed=b)
+        _assert_close(_run(torch_cuda, lift, host), _oracle(lift, host))
 
 
 @pytest.mark.parametrize("Np,Nfp", [(4, 3), (20, 10), (35, 15), (56, 21)])
