@@ -42,7 +42,11 @@
 
 namespace fe {
 
-template <int NP, int M, int MODE = 0, int ND = 3>
+// ALDS: the big-tile A fragments live in LDS (fragment layout, conflict-free 512-byte reads)
+// instead of registers.  At Np = 56 (tetrahedra p = 5) they are 126 doubles per lane -- the whole
+// register file -- while one fragment read per 64-cycle MFMA is only 6 % of the LDS bandwidth.
+// The block then owns most of a CU's LDS: one block (4 waves) per CU.
+template <int NP, int M, int MODE = 0, int ND = 3, bool ALDS = false>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int NPLANES = MODE == 0 ? ND : 1;  // u planes per tile
@@ -69,17 +73,19 @@ struct DivGeom {
     static constexpr int ASMALL_D = NC * KSJ * NS * 16; // [k-step][group][g][row] doubles, per block
     static constexpr int OP_D = NC * NP * NP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
-    static constexpr int LDS_BYTES = (WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8) + ASMALL_D * 8;
+    static constexpr int ABIG_D = ALDS ? BT * KSJ * NC * 64 : 0;   // [(jq, r)][t][lane] doubles, per block
+    static constexpr int LDS_BYTES = (WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8) + (ASMALL_D + ABIG_D) * 8;
+    static constexpr int BLOCKS_PER_CU = ALDS ? 1 : 2;
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
+    static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
-    using G = DivGeom<NP, M, MODE, ND>;
+    using G = DivGeom<NP, M, MODE, ND, ALDS>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -91,8 +97,9 @@ __device__ __forceinline__ void div3d_mfma_body(
     //      A[row 16t + n][k = g];  4x4x4_4b group q: lane (g, n) supplies block n/4, row
     //      16 BT + 4q + n%4, k = g -- identical for the four blocks, kept once in LDS.
     constexpr int NC = G::NC;
-    double abig[G::BT > 0 ? G::BT : 1][G::KSJ][NC];
-    double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - G::ASMALL_D * 8));
+    double abig[(G::BT > 0 && !ALDS) ? G::BT : 1][ALDS ? 1 : G::KSJ][ALDS ? 1 : NC];
+    double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - (G::ASMALL_D + G::ABIG_D) * 8));
+    double* afr = asmall + G::ASMALL_D;   // ALDS: big-tile fragments [(jq * NC + r) * BT + t][lane]
     {
         double* dl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D>(D, dl);
@@ -107,7 +114,12 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t) {
                     const double v = col[r * (NP * NP) + 16 * t * istride];
-                    abig[t][jq][r] = (j < NP) ? v : 0.0;
+                    if (ALDS) {
+                        // every wave builds the same fragments: wave w stores those of the k-quads jq = w mod 4
+                        if ((jq & 3) == wave) afr[((jq * NC + r) * G::BT + t) * 64 + lane] = (j < NP) ? v : 0.0;
+                    } else {
+                        abig[t][jq][r] = (j < NP) ? v : 0.0;
+                    }
                 }
         }
         for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
@@ -118,6 +130,11 @@ __device__ __forceinline__ void div3d_mfma_body(
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
     const double* as_lane = asmall + g * 4 + (n & 3);
+    const double* af_lane = afr + lane;
+    auto a_big = [&](int t, int jq, int r) -> double {
+        if constexpr (ALDS) return af_lane[((jq * NC + r) * G::BT + t) * 64];
+        else return abig[t][jq][r];
+    };
 
     remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
         for (int k = 0; k < nb; ++k) {
@@ -245,7 +262,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     for (int r = 0; r < NC; ++r) {
 #pragma unroll
                         for (int t = 0; t < G::BT; ++t)
-                            acc[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[m][jq][0], acc[r][t], 0, 0, 0);
+                            acc[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bfrag[m][jq][0], acc[r][t], 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < G::NS; ++q)
                             accs[r][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16],
@@ -305,7 +322,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                     for (int r = 0; r < NC; ++r) sum += bfrag[m][jq][r];
 #pragma unroll
-                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{sum, sum, sum, abig[t][0][0]};
+                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{sum, sum, sum, a_big(t, 0, 0)};
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) accs[q] = sum;
             } else {
@@ -315,7 +332,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     for (int r = 0; r < NC; ++r) {
 #pragma unroll
                         for (int t = 0; t < G::BT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bfrag[m][jq][r], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bfrag[m][jq][r], acc[t], 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < G::NS; ++q)
                             accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16],
@@ -353,11 +370,11 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
 }
 
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false>
 __global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes) {
-    div3d_mfma_body<NP, M, kDbg, MODE, ND>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
+    div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -98,6 +98,22 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
+// grad of tetrahedra p = 5 (Np = 56): grad by components with the A fragments in LDS, one block per CU
+int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
+                   hipStream_t s, bool* launched) {
+    using G = fe::DivGeom<56, 1, 4, 3, true>;
+    const int64_t nTiles = E / G::TEL;
+    *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
+    if (nTiles == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
+                       dim3(256), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+    return FE_OK;
+}
+
 // ---- the LDS-tiled VALU kernel (fe_tiled.h): any shape whose operator fits in LDS
 constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
 
@@ -328,7 +344,7 @@ fe::GradFields grad_fields(const double* J, const double* const* u, double* cons
 // are those of a plain grad (one [3][3][E] array, [3][E][Np] outputs).
 int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const double* D, int nb, int nx,
                        int64_t E, int Np, int opT, int variant, hipStream_t s) {
-    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4 || (Np == 56 && Jfull);
     fe::FieldPtrs Pt = {};
     for (int k = 0; k < nb; ++k) { Pt.v[k] = P.u[k]; Pt.out[k] = P.out[k][0]; }
     const fe::TiledArgs ta = tiled_args(FE_FAMILY_GRAD, Jfull, D, Pt, nb, E, 3, Np, 0, 0, opT, 0, 0);
@@ -337,6 +353,15 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
                              &path))
         return rc;
     if (path == kPathTiled) return launch_tiled(ta, s);
+    if (path == kPathMfma && Np == 56) {   // p = 5: too many A fragments for the row-permuted kernel
+        bool launched = false;
+        if (int rc = launch_grad_p5(Jfull, D, Pt, nb, E, opT, s, &launched)) return rc;
+        if (launched) {
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
+        return tiled_fits(ta) ? launch_tiled(ta, s) : fail(FE_EUNSUPPORTED, "grad: no kernel for this size");
+    }
     int64_t e_done = 0;
     if (path == kPathMfma) {
         int dbg = 0;

@@ -82,9 +82,12 @@ def test_forced_mfma_variant(torch_cuda, fam):
     expr = FAMILIES[fam]()
     host = generate_host_input_arrays(expr, 4096, np_seed=5)
     _assert_close(_run(torch_cuda, expr, host, transform={"variant": "mfma"}), _oracle(expr, host))
-    with pytest.raises(NotImplementedError):   # FE_EUNSUPPORTED: Np = 56 (p = 5) is not compiled for MFMA
-        e56 = dg.grad(56)
-        _run(torch_cuda, e56, generate_host_input_arrays(e56, 64), transform="mfma")
+    with pytest.raises(NotImplementedError):   # FE_EUNSUPPORTED: Np = 84 (p = 6) is not compiled for MFMA
+        e84 = dg.grad(84)
+        _run(torch_cuda, e84, generate_host_input_arrays(e84, 64), transform="mfma")
+    with pytest.raises(NotImplementedError):   # nor is div at p = 5 (its three u planes leave no LDS for the operator)
+        d56 = dg.div(56)
+        _run(torch_cuda, d56, generate_host_input_arrays(d56, 64), transform="mfma")
 
 
 @pytest.mark.parametrize("Np", [4, 10, 20])
@@ -344,6 +347,16 @@ def test_two_dimensional_operators(torch_cuda, Np, Nfp, E):
                                                      f2.array(f"v{k}", (3, "E", Nfp))] for k in range(b)])
         host = generate_host_input_arrays(lift, E, np_seed=b)
         _assert_close(_run(torch_cuda, lift, host), _oracle(lift, host))
+
+
+@pytest.mark.parametrize("E", [1, 15, 16, 17, 63, 64, 65, 1003, 5000])
+def test_grad_p5_on_the_matrix_cores(torch_cuda, E):
+    # Np = 56: grad by components with the A fragments in LDS (one block per CU); plain, transposed, batched
+    for expr in (dg.grad(56), dg.grad_t(56), dg.batched_grad(3, 56)):
+        host = generate_host_input_arrays(expr, E, np_seed=E)
+        ref = _oracle(expr, host)
+        for v in ("auto", "mfma", "tiled", "generic"):
+            _assert_close(_run(torch_cuda, expr, host, transform=v), ref)
 
 
 @pytest.mark.parametrize("Np,Nfp", [(4, 3), (20, 10), (35, 15), (56, 21)])
