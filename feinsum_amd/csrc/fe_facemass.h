@@ -25,7 +25,10 @@ namespace fe {
 
 constexpr int kFmNf = 4;   // faces of a tetrahedron (the default NF); triangles: NF = 3
 
-template <int NP, int NFP, int M, int NF = kFmNf>
+// ALDS: all A fragments in LDS (fragment layout) instead of registers -- tetrahedra p = 5
+// (Np = 56, Nfp = 21): 105 doubles of A per lane plus the B fragments exceed the register file.
+// One block per CU then (see DivGeom).
+template <int NP, int NFP, int M, int NF = kFmNf, bool ALDS = false>
 struct FmGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int K = NF * NFP;
@@ -47,19 +50,22 @@ struct FmGeom {
     static constexpr int WAVES = 4;
     static constexpr int OP_D = NF * NP * NFP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
-    static constexpr int LDS_BYTES = WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8;
+    static constexpr int AFR_BIG_D = ALDS ? BT * KS * 64 : 0;      // [ks][t][lane]
+    static constexpr int AFR_D = AFR_BIG_D + (ALDS ? NS * KS * 16 : 0);   // + [ks][q][g][row]: 16 distinct values per group
+    static constexpr int LDS_BYTES = (WAVE_BYTES > OP_D * 8 ? WAVE_BYTES : OP_D * 8) + AFR_D * 8;
+    static constexpr int BLOCKS_PER_CU = ALDS ? 1 : 2;
     static_assert((TEL * NFP) % 2 == 0, "slabs are moved in 16-byte chunks");
     static_assert(2 * UNIT_STORES + UNIT_LOADS + J_INSTR <= 60, "counted vmcnt must fit the 6-bit field");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
+    static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
 };
 
 // UNIT_LOADS x 16-byte LDS-DMA for the field slabs (+ J_INSTR for J at a tile start).
-template <int NP, int NFP, int M, bool kWithJ, int NF = kFmNf>
+template <int NP, int NFP, int M, bool kWithJ, int NF = kFmNf, bool ALDS = false>
 __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J,
                                                     const double* __restrict__ vk, int64_t E,
                                                     int64_t tile, int lane, unsigned lds_v,
                                                     unsigned lds_j, int jfe) {
-    using G = FmGeom<NP, NFP, M, NF>;
+    using G = FmGeom<NP, NFP, M, NF, ALDS>;
     const int64_t e0 = tile * G::TEL;
     const char* vb = reinterpret_cast<const char*>(vk) + e0 * (NFP * 8) + lane * 16;
 #pragma unroll
@@ -84,11 +90,11 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 }
 
 // bid / nblk: see grad3d_mfma_body.
-template <int NP, int NFP, int M, int NB, int NF = kFmNf>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false>
 __device__ __forceinline__ void facemass_mfma_body(
     const double* __restrict__ J, const double* __restrict__ R, const FieldPtrs& P, int64_t E,
     int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
-    using G = FmGeom<NP, NFP, M, NF>;
+    using G = FmGeom<NP, NFP, M, NF, ALDS>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,8 +106,10 @@ __device__ __forceinline__ void facemass_mfma_body(
     // ---- per-lane K decomposition: k = 4 ks + g = NFP f + j
     int voff[G::KS];   // offset of v[f][sub-tile 0 element n][j] inside a unit slab
     int joff[G::KS];   // offset of J[sub-tile 0 element n][f] inside the J tile
-    double abig[G::BT > 0 ? G::BT : 1][G::KS];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
-    double asmall[G::NS > 0 ? G::NS : 1][G::KS]; // 4x4x4_4b group q: block n/4, row 16 BT + 4q + n%4, k = g
+    double abig[(G::BT > 0 && !ALDS) ? G::BT : 1][ALDS ? 1 : G::KS];   // 16x16x4: lane (g, n) supplies A[row 16t + n][k = g]
+    double asmall[(G::NS > 0 && !ALDS) ? G::NS : 1][ALDS ? 1 : G::KS]; // 4x4x4_4b group q: block n/4, row 16 BT + 4q + n%4, k = g
+    double* afr = reinterpret_cast<double*>(smem + (G::LDS_BYTES - G::AFR_D * 8));   // ALDS: big tiles [ks][t][lane] ...
+    double* afs = afr + G::AFR_BIG_D;                                                //       ... small groups [ks][q][g][row]
     {
         // R goes through LDS once per block (see stage_operator)
         double* rl = reinterpret_cast<double*>(smem);
@@ -124,17 +132,36 @@ __device__ __forceinline__ void facemass_mfma_body(
             for (int t = 0; t < G::BT; ++t) {
                 const int i = 16 * t + n;
                 const double a = rl[ridx(f, i, j)];
-                abig[t][ks] = kok ? a : 0.0;
+                if (ALDS) {   // every wave builds the same fragments: wave w stores those of k-steps ks = w mod 4
+                    if ((ks & 3) == wave) afr[(ks * G::BT + t) * 64 + lane] = kok ? a : 0.0;
+                } else {
+                    abig[t][ks] = kok ? a : 0.0;
+                }
             }
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) {
                 const int i3 = 16 * G::BT + 4 * q + (n & 3), i3c = i3 < NP ? i3 : 0;
                 const double a3 = rl[ridx(f, i3c, j)];
-                asmall[q][ks] = (i3 < NP && kok) ? a3 : 0.0;
+                if (ALDS) {
+                    if ((ks & 3) == wave && n < 4) afs[(ks * G::NS + q) * 16 + g * 4 + n] = (i3 < NP && kok) ? a3 : 0.0;
+                } else {
+                    asmall[q][ks] = (i3 < NP && kok) ? a3 : 0.0;
+                }
             }
         }
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
+
+    const double* af_lane = afr + lane;
+    const double* as_lane = afs + g * 4 + (n & 3);
+    auto a_big = [&](int t, int ks) -> double {
+        if constexpr (ALDS) return af_lane[(ks * G::BT + t) * 64];
+        else return abig[t][ks];
+    };
+    auto a_small = [&](int q, int ks) -> double {
+        if constexpr (ALDS) return as_lane[(ks * G::NS + q) * 16];
+        else return asmall[q][ks];
+    };
 
     const unsigned lds_v0 = lds_addr_uniform(L->v[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
@@ -152,8 +179,8 @@ __device__ __forceinline__ void facemass_mfma_body(
     if (first >= tEnd) return;
 
     // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<NP, NFP, M, true, NF>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
-    fm_issue_unit_loads<NP, NFP, M, false, NF>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
 
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
@@ -202,10 +229,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 const int64_t tile2 = tile + stride * ((k + 2) / NB);
                 if (tile2 < tEnd) {
                     if (k2 == 0)
-                        fm_issue_unit_loads<NP, NFP, M, true, NF>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS>(J, P.v[k2], E, tile2, lane,
                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                     else
-                        fm_issue_unit_loads<NP, NFP, M, false, NF>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS>(J, P.v[k2], E, tile2, lane,
                                                                lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                 }
             }
@@ -223,10 +250,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 for (int ks = 0; ks < G::KS; ++ks) {
 #pragma unroll
                     for (int t = 0; t < G::BT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][ks], bfrag[m][ks], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, ks), bfrag[m][ks], acc[t], 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < G::NS; ++q)
-                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(asmall[q][ks], bfrag[m][ks], accs[q], 0, 0, 0);
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_small(q, ks), bfrag[m][ks], accs[q], 0, 0, 0);
                 }
 
                 // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e][16t + g + 4q'];
@@ -258,11 +285,11 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
 }
 
-template <int NP, int NFP, int M, int NB, int NF = kFmNf>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false>
 __global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
     int64_t nTiles, int jfe, int rlayout) {
-    facemass_mfma_body<NP, NFP, M, NB, NF>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
+    facemass_mfma_body<NP, NFP, M, NB, NF, ALDS>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -292,28 +292,29 @@ int launch_matapply(const double* J, const double* D, const fe::FieldPtrs& P, in
              : launch_matapply_mode<NP, M, 3>(J, D, P, nb, E, opT, s, e_done);
 }
 
-template <int NP, int NFP, int M, int NB, int NF = fe::kFmNf>
+template <int NP, int NFP, int M, int NB, int NF = fe::kFmNf, bool ALDS = false>
 int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
-    using G = fe::FmGeom<NP, NFP, M, NF>;
+    using G = fe::FmGeom<NP, NFP, M, NF, ALDS>;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF>, G::LDS_BYTES); });
+        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
-    const unsigned grid = persistent_grid(nTiles, G::WAVES);
-    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, R,
-                       P, E, nTiles, jfe, rifj);
+    unsigned grid = persistent_grid(nTiles, G::WAVES);
+    if (G::BLOCKS_PER_CU == 1 && grid > (unsigned)device_cu_count()) grid = (unsigned)device_cu_count();
+    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                       J, R, P, E, nTiles, jfe, rifj);
     return FE_OK;
 }
 
 // One MFMA launch for a group of nb fields (2 <= nb <= kMaxGroup of the geometry).
-template <int NP, int NFP, int M, int NF = fe::kFmNf>
+template <int NP, int NFP, int M, int NF = fe::kFmNf, bool ALDS = false>
 int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, int64_t E, int64_t nTiles,
               int jfe, int rifj, hipStream_t s) {
     switch (nb) {
-        case 2: return launch_fm_nb<NP, NFP, M, 2, NF>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 3: return launch_fm_nb<NP, NFP, M, 3, NF>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 4: return launch_fm_nb<NP, NFP, M, 4, NF>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 2: return launch_fm_nb<NP, NFP, M, 2, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 3: return launch_fm_nb<NP, NFP, M, 3, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 4: return launch_fm_nb<NP, NFP, M, 4, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
         default: break;
     }
     if constexpr (NP == 35 && NF == fe::kFmNf) {   // p = 4, the headline order: groups of up to 8 fields
@@ -487,6 +488,7 @@ inline bool fm_mfma_geometry(int Np, int nf, int Nfp, FmChoice* c) {
         return false;
     }
     if (nf != fe::kFmNf) return false;
+    if (Np == 56 && Nfp == 21) { *c = {4, 16}; return true; }   // p = 5: A fragments in LDS
     if (Np == 35 && Nfp == 15) { *c = {8, 16}; return true; }
     if (Np == 20 && Nfp == 10) { *c = {4, 16}; return true; }
     if (Np == 10 && Nfp == 6) { *c = {4, 32}; return true; }
@@ -936,6 +938,7 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
                 }
             } else {
                 switch (Np) {   // tetrahedra
+                    case 56: rc = launch_fm<56, 21, 1, fe::kFmNf, true>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
                     case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
                     case 20: rc = launch_fm<20, 10, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
                     case 10: rc = launch_fm<10, 6, 2>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
@@ -968,7 +971,7 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
                     const double* const* f, double* const* lift, int64_t E, int32_t Np, int32_t nf,
                     int32_t Nfp, int32_t b, int32_t fm_layout_flags, int32_t variant, void* stream) {
     FmChoice geo{0, 16};
-    const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && nf == fe::kFmNf &&
+    const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && nf == fe::kFmNf && Np != 56 &&
                        fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
                        b <= 4 && f && lift && E > 0 && !(fm_layout_flags & ~7);
     if (!fused) {   // three launches (argument checks included)
