@@ -64,9 +64,14 @@ struct DivGeom {
     static constexpr int J_ROW_CHUNKS = TEL / 2, J_CHUNKS = NJ * J_ROW_CHUNKS, J_INSTR = (J_CHUNKS + 63) / 64;
     static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
     static constexpr int LOADS = NPLANES * P_INSTR + J_INSTR, STORES = NOUT * M * SUB_INSTR;
+    // ALDS div ("plane streaming"): the ND u planes of a tile pass through TWO plane buffers one after
+    // the other and the second buffer doubles as the output transposition buffer -- with all ND planes
+    // and a separate o buffer resident (86 + 29 KB for four waves at Np = 56) there is no room for
+    // the fragments.
+    static constexpr bool STREAM = ALDS && MODE == 0;
     struct WaveLds {
-        double u[NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
-        double o[SUB_D];              // output transposition buffer (one 16-element sub-tile)
+        double u[STREAM ? 2 : NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
+        double o[STREAM ? 2 : SUB_D];              // output transposition buffer (one 16-element sub-tile)
         double j[NJ > 0 ? NJ * TEL : 2];   // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s]; MODE 2: J[..])
     };
     static constexpr int WAVES = 4;
@@ -78,6 +83,7 @@ struct DivGeom {
     static constexpr int BLOCKS_PER_CU = ALDS ? 1 : 2;
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
     static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
+    static_assert(!STREAM || M == 1, "plane streaming is written for one sub-tile per wave tile");
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
@@ -177,6 +183,116 @@ __device__ __forceinline__ void div3d_mfma_body(
         }
     };
     int64_t tile = (int64_t)bid * G::WAVES + wave;
+    if constexpr (G::STREAM) {
+        // ---- plane streaming (see DivGeom): per (tile, field) unit
+        //   L(p0), L(J) | L(p1) -> B += plane 0 | L(p2) -> B += plane 1 -> B += plane 2 | L(p0', J') | MFMAs | stores
+        const unsigned lds_a = lds_addr_uniform(L->u[0]), lds_b = lds_addr_uniform(L->u[1]);
+        auto issue_plane = [&](int64_t t, int fk, int x, unsigned lds) {
+            const char* up = reinterpret_cast<const char*>(field_in(P, fk)) + ((int64_t)x * E + t * G::TEL) * (NP * 8) +
+                             lane * 16;
+#pragma unroll
+            for (int c = 0; c < G::P_INSTR; ++c)
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS) glds16_nt(up + c * 1024, lds + c * 1024);
+        };
+        auto issue_j = [&](int64_t t) {
+            const char* jb = reinterpret_cast<const char*>(J) + t * G::TEL * 8;
+#pragma unroll
+            for (int c = 0; c < G::J_INSTR; ++c) {
+                const int q = c * 64 + lane;
+                const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
+                if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS)
+                    glds16(jb + ((int64_t)row * E) * 8 + col * 16, lds_j + c * 1024);
+            }
+        };
+        static_assert(ND == 3, "three planes");
+        bool first = true;
+        int fk = 0;
+        if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
+        while (tile < tEnd) {
+            double* const out = field_out(P, fk);
+            const bool next_new_tile = (fk + 1 == nb);
+            const int64_t nt = next_new_tile ? tile + stride : tile;
+            const int nk = next_new_tile ? 0 : fk + 1;
+            issue_plane(tile, fk, 1, lds_b);                 // the previous unit's o (= buffer b) has been read out
+            if (first) wait_vmcnt<G::P_INSTR>();             // p0 and J landed; younger: S(previous), L(p1)
+            else wait_vmcnt<G::STORES + G::P_INSTR>();
+            first = false;
+            double jac[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
+            double bfrag[G::KSJ][3];
+            auto add_plane = [&](int x, const double* up) {
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq) {
+                    const int j = 4 * jq + g;
+                    const double v = j < NP ? up[n * NP + (j < NP ? j : 0)] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) bfrag[jq][r] = x == 0 ? jac[r] * v : bfrag[jq][r] + jac[x * 3 + r] * v;
+                }
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the plane is in registers: its buffer may be refilled
+            };
+            add_plane(0, L->u[0]);
+            issue_plane(tile, fk, 2, lds_a);
+            wait_vmcnt<G::P_INSTR>();                         // p1 landed; younger: L(p2)
+            add_plane(1, L->u[1]);
+            wait_vmcnt<0>();
+            add_plane(2, L->u[0]);
+            if (nt < tEnd) { issue_plane(nt, nk, 0, lds_a); issue_j(nt); }
+
+            v4d acc[G::BT];
+            double accs[G::NS > 0 ? G::NS : 1];
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bfrag[jq][r], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16], bfrag[jq][r],
+                                                                     accs[q], 0, 0, 0);
+                }
+            double* ob = L->u[1];                             // buffer b as the output transposition buffer
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) {
+                const int i = 16 * G::BT + 4 * q + g;
+                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+            }
+            wave_lds_fence();
+            double* op = out + tile * G::TEL * NP;
+            v2d held[G::SUB_INSTR];
+#pragma unroll
+            for (int c = 0; c < G::SUB_INSTR; ++c) {
+                const int qc = c * 64 + lane;
+                held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) ? *reinterpret_cast<const v2d*>(ob + 2 * qc)
+                                                                              : v2d{0.0, 0.0};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // o is in registers before buffer b is refilled
+#pragma unroll
+            for (int c = 0; c < G::SUB_INSTR; ++c) {
+                const int qc = c * 64 + lane;
+                if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                    __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+            }
+            wave_lds_fence();
+            fk = nk;
+            tile = nt;
+        }
+        return;
+    }
     bool first = true;
     if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
     const bool younger_half = bid >= (nblk + 1) / 2;

@@ -114,6 +114,22 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
     return FE_OK;
 }
 
+// div of tetrahedra p = 5: the A fragments in LDS and the u planes streamed through two buffers
+int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
+                  hipStream_t s, bool* launched) {
+    using G = fe::DivGeom<56, 1, 0, 3, true>;
+    const int64_t nTiles = E / G::TEL;
+    *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
+    if (nTiles == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>, G::LDS_BYTES); });
+    if (attr_rc != FE_OK) return attr_rc;
+    const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
+                       dim3(256), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+    return FE_OK;
+}
+
 // ---- the LDS-tiled VALU kernel (fe_tiled.h): any shape whose operator fits in LDS
 constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
 
@@ -659,12 +675,21 @@ int fe_div3d_batched_f64(const double* J, const double* D, const double* const* 
         return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    const bool mfma_ok = Np == 56 || Np == 35 || Np == 20 || Np == 10 || Np == 4;
     const fe::TiledArgs ta = tiled_args(FE_FAMILY_DIV, J, D, P, b, E, 3, Np, 0, 0, opT, 0, 0);
     KernelPath path;
     if (int rc = choose_path(variant >= 1000 ? FE_VARIANT_MFMA : variant, mfma_ok, tiled_fits(ta), "div", Np, &path))
         return rc;
     if (path == kPathTiled) return launch_tiled(ta, s);
+    if (path == kPathMfma && Np == 56) {   // p = 5
+        bool launched = false;
+        if (int rc = launch_div_p5(J, D, P, b, E, opT, s, &launched)) return rc;
+        if (launched) {
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
+        return tiled_fits(ta) ? launch_tiled(ta, s) : fail(FE_EUNSUPPORTED, "div: no kernel for this size");
+    }
     int64_t e_done = 0;
     if (path == kPathMfma) {
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only

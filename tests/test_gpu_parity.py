@@ -85,9 +85,6 @@ def test_forced_mfma_variant(torch_cuda, fam):
     with pytest.raises(NotImplementedError):   # FE_EUNSUPPORTED: Np = 84 (p = 6) is not compiled for MFMA
         e84 = dg.grad(84)
         _run(torch_cuda, e84, generate_host_input_arrays(e84, 64), transform="mfma")
-    with pytest.raises(NotImplementedError):   # nor is div at p = 5 (its three u planes leave no LDS for the operator)
-        d56 = dg.div(56)
-        _run(torch_cuda, d56, generate_host_input_arrays(d56, 64), transform="mfma")
 
 
 @pytest.mark.parametrize("Np", [4, 10, 20])
@@ -350,9 +347,11 @@ def test_two_dimensional_operators(torch_cuda, Np, Nfp, E):
 
 
 @pytest.mark.parametrize("E", [1, 15, 16, 17, 63, 64, 65, 1003, 5000])
-def test_grad_p5_on_the_matrix_cores(torch_cuda, E):
-    # Np = 56: grad by components with the A fragments in LDS (one block per CU); plain, transposed, batched
-    for expr in (dg.grad(56), dg.grad_t(56), dg.batched_grad(3, 56)):
+def test_p5_on_the_matrix_cores(torch_cuda, E):
+    # Np = 56: the A fragments in LDS, one block per CU -- grad by components, div with its u planes
+    # streamed through two buffers, face-mass; plain, transposed, batched
+    for expr in (dg.grad(56), dg.grad_t(56), dg.batched_grad(3, 56), dg.div(56), dg.div_t(56), dg.batched_div(3, 56),
+                 dg.face_mass(4, Np=56, Nfp=21), dg.face_mass_jfi_fe(3, Np=56, Nfp=21)):
         host = generate_host_input_arrays(expr, E, np_seed=E)
         ref = _oracle(expr, host)
         for v in ("auto", "mfma", "tiled", "generic"):
