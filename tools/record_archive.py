@@ -45,13 +45,14 @@ for K in (4, 10, 20, 35):
 cases += [(f.einsum("fej,fej->fej", f.array("A", (4, "E", K)), f.array("B", (4, "E", K))), ("generic",))
           for K in (3, 6, 10, 15)]
 
-# triangles p = 1..5 (MFMA) and tetrahedra p = 5 (tiled VALU kernel)
+# triangles p = 1..5 and tetrahedra p = 5 (MFMA; the tiled VALU kernel beside it)
 for Np, Nfp in ((3, 2), (6, 3), (10, 4), (15, 5), (21, 6)):
     cases += [(f.einsum("xre,rij,ej->xei", f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np)), f.array("u", ("E", Np))), ("mfma",)),
               (f.einsum("xre,rij,xej->ei", f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np)), f.array("u", (2, "E", Np))), ("mfma",)),
               (f.batched_einsum("ef,fij,fej->ei", [[f.array("J", ("E", 3)), f.array("R", (3, Np, Nfp)),
                                                     f.array(f"v{k}", (3, "E", Nfp))] for k in range(3)]), ("mfma",))]
-cases += [(dg.grad(56), ("tiled", "generic")), (dg.div(56), ("tiled",)), (dg.face_mass(4, Np=56, Nfp=21), ("tiled",)),
+cases += [(dg.grad(56), ("mfma", "tiled", "generic")), (dg.div(56), ("mfma", "tiled")),
+          (dg.face_mass(4, Np=56, Nfp=21), ("mfma", "tiled")),
           (dg.mass_apply(4, 56), ("mfma",)), (dg.grad(), ("tiled",)), (dg.div(), ("tiled",)), (dg.face_mass(), ("tiled",))]
 
 q = f.DeviceQueue(0)
