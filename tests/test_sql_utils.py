@@ -89,5 +89,7 @@ def test_shipped_archive_has_the_headline_facts():
     if not os.path.exists(sql_utils.DEFAULT_DB):
         pytest.skip("no shipped archive yet")
     dev = f.FakeCLDevice("AMD Instinct MI355X")
-    for expr in (dg.grad(), dg.div(), dg.face_mass()):
-        assert dict(sql_utils.retrieve(expr, dev))["variant"] == "mfma"
+    tri_grad = f.einsum("xre,rij,ej->xei", f.array("J", (2, 2, "E")), f.array("R", (2, 15, 15)), f.array("u", ("E", 15)))
+    for expr in (dg.grad(), dg.div(), dg.face_mass(), dg.grad(56), dg.div(56), dg.face_mass(4, Np=56, Nfp=21), tri_grad,
+                 dg.mass_apply(4), dg.cross_product_batch()):
+        assert dict(sql_utils.retrieve(expr, dev))["variant"] == "mfma", expr.get_subscripts()
