@@ -266,22 +266,24 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     return FE_OK;
 }
 
-template <int NP, int M>
+template <int NP, int M, bool ALDS = false>
 int launch_divcomp(const double* J, const double* D, const double* u, double* out, int64_t E,
                    int opT, int jes, hipStream_t s, int64_t* e_done) {
-    using G = fe::DivGeom<NP, M, 1>;
+    using G = fe::DivGeom<NP, M, 1, 3, ALDS>;
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1>, G::LDS_BYTES); });
+    const int attr_rc =
+        once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
     fe::FieldPtrs P = {};
     P.v[0] = u;
     P.out[0] = out;
-    const unsigned grid = persistent_grid(nTiles, G::WAVES);
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, P, 1,
-                       E, nTiles, opT, jes);
+    unsigned grid = persistent_grid(nTiles, G::WAVES);
+    if (G::BLOCKS_PER_CU == 1 && grid > (unsigned)device_cu_count()) grid = (unsigned)device_cu_count();
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, P,
+                       1, E, nTiles, opT, jes);
     return FE_OK;
 }
 
@@ -773,7 +775,7 @@ int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* 
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, jes = (op_flags & FE_OP_J_ES) ? 1 : 0;
-    const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    const bool mfma_ok = Np == 56 || Np == 35 || Np == 20 || Np == 10 || Np == 4;
     fe::FieldPtrs Pt = {};
     Pt.v[0] = u;
     Pt.out[0] = out;
@@ -785,6 +787,7 @@ int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* 
     if (path == kPathMfma) {
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
+            case 56: rc = launch_divcomp<56, 1, true>(J, D, u, out, E, opT, jes, s, &e_done); break;   // p = 5: A in LDS
             case 35: rc = launch_divcomp<35, 1>(J, D, u, out, E, opT, jes, s, &e_done); break;
             case 20: rc = launch_divcomp<20, 2>(J, D, u, out, E, opT, jes, s, &e_done); break;
             case 10: rc = launch_divcomp<10, 4>(J, D, u, out, E, opT, jes, s, &e_done); break;

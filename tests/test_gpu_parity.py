@@ -131,13 +131,13 @@ def test_transposed_operators_lower_orders(torch_cuda, Np):
         _assert_close(_run(torch_cuda, expr, host, transform="generic"), ref)
 
 
-@pytest.mark.parametrize("Np", [4, 10, 20, 35, 56])
+@pytest.mark.parametrize("Np", [4, 10, 20, 35, 56, 84])
 @pytest.mark.parametrize("E", [31, 32, 97, 1003])
 def test_div_components(torch_cuda, Np, E):
     # 'se,sij,ej->ei' x 3 (test/test_codegen.py:34-66) and its 'es' / transposed-operator layouts
     import feinsum_amd as f2
 
-    variants = ["auto", "generic"] + (["mfma"] if Np != 56 else [])
+    variants = ["auto", "generic"] + (["mfma"] if Np != 84 else [])
     for subs, jshape in (("se,sij,ej->ei", (3, "E")), ("es,sij,ej->ei", ("E", 3)), ("se,sji,ej->ei", (3, "E"))):
         expr = f2.batched_einsum(subs, [[f2.array("J" + c, jshape), f2.array("R", (3, Np, Np)),
                                          f2.array("u" + c, ("E", Np))] for c in "xyz"])
