@@ -106,20 +106,20 @@ __device__ __forceinline__ void wave_lds_fence() {
 // block's LDS, all threads, coalesced.  Caller synchronises.  (2048 waves each gathering their
 // MFMA fragments of the same ~30 KB straight from L2 cost up to 18 us of prologue; staged once
 // per block it is ~5 us and the whole kernel ran 9 % faster in A/B.)
-template <int N>
+template <int N, int THREADS = 256>
 __device__ __forceinline__ void stage_operator(const double* __restrict__ g, double* lds) {
-    // 256-thread blocks; all loads are issued before the first LDS write so that their latencies
-    // overlap (a plain copy loop waits for each load in turn: ~15 dependent L2 round trips).
-    constexpr int kPer = (N + 255) / 256;
+    // all loads are issued before the first LDS write so that their latencies overlap (a plain
+    // copy loop waits for each load in turn: ~15 dependent L2 round trips).
+    constexpr int kPer = (N + THREADS - 1) / THREADS;
     double tmp[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int i = threadIdx.x + k * 256;
+        const int i = threadIdx.x + k * THREADS;
         tmp[k] = (i < N) ? g[i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int i = threadIdx.x + k * 256;
+        const int i = threadIdx.x + k * THREADS;
         if (i < N) lds[i] = tmp[k];
     }
 }

@@ -46,7 +46,11 @@ namespace fe {
 // instead of registers.  At Np = 56 (tetrahedra p = 5) they are 126 doubles per lane -- the whole
 // register file -- while one fragment read per 64-cycle MFMA is only 6 % of the LDS bandwidth.
 // The block then owns most of a CU's LDS: one block (4 waves) per CU.
-template <int NP, int M, int MODE = 0, int ND = 3, bool ALDS = false>
+// W8 (with ALDS, MODE 4): eight waves per block share the fragments; a wave's u tile and its output
+// transposition buffer are the same LDS (the next tile is requested after the stores), which is
+// what lets two waves per SIMD fit beside 75 KB of fragments -- the partner wave's MFMAs cover
+// the exposed load.
+template <int NP, int M, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int NPLANES = MODE == 0 ? ND : 1;  // u planes per tile
@@ -69,12 +73,14 @@ struct DivGeom {
     // and a separate o buffer resident (86 + 29 KB for four waves at Np = 56) there is no room for
     // the fragments.
     static constexpr bool STREAM = ALDS && MODE == 0;
+    static_assert(!W8 || (ALDS && MODE == 4 && M == 1), "eight-wave blocks: grad by components, A in LDS");
     struct WaveLds {
         double u[STREAM ? 2 : NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
-        double o[STREAM ? 2 : SUB_D];              // output transposition buffer (one 16-element sub-tile)
+        double o[(STREAM || W8) ? 2 : SUB_D];      // output transposition buffer (one 16-element sub-tile)
         double j[NJ > 0 ? NJ * TEL : 2];   // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s]; MODE 2: J[..])
     };
-    static constexpr int WAVES = 4;
+    static constexpr int WAVES = W8 ? 8 : 4;
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int ASMALL_D = NC * KSJ * NS * 16; // [k-step][group][g][row] doubles, per block
     static constexpr int OP_D = NC * NP * NP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
@@ -87,11 +93,11 @@ struct DivGeom {
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
-    using G = DivGeom<NP, M, MODE, ND, ALDS>;
+    using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -108,7 +114,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     double* afr = asmall + G::ASMALL_D;   // ALDS: big-tile fragments [(jq * NC + r) * BT + t][lane]
     {
         double* dl = reinterpret_cast<double*>(smem);
-        stage_operator<G::OP_D>(D, dl);
+        stage_operator<G::OP_D, G::THREADS>(D, dl);
         __syncthreads();
         const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored [r][j][i]
 #pragma unroll
@@ -122,13 +128,13 @@ __device__ __forceinline__ void div3d_mfma_body(
                     const double v = col[r * (NP * NP) + 16 * t * istride];
                     if (ALDS) {
                         // every wave builds the same fragments: wave w stores those of the k-quads jq = w mod 4
-                        if ((jq & 3) == wave) afr[((jq * NC + r) * G::BT + t) * 64 + lane] = (j < NP) ? v : 0.0;
+                        if (jq % G::WAVES == wave) afr[((jq * NC + r) * G::BT + t) * 64 + lane] = (j < NP) ? v : 0.0;
                     } else {
                         abig[t][jq][r] = (j < NP) ? v : 0.0;
                     }
                 }
         }
-        for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += 256) {
+        for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += G::THREADS) {
             const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
             const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
             asmall[idx] = (j < NP && i < NP) ? dl[r * (NP * NP) + i * istride + j * jstride] : 0.0;
@@ -288,6 +294,90 @@ __device__ __forceinline__ void div3d_mfma_body(
                     __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
             }
             wave_lds_fence();
+            fk = nk;
+            tile = nt;
+        }
+        return;
+    }
+    if constexpr (W8) {
+        // ---- eight waves per block (see DivGeom): wait u, J -> B, J to registers -> MFMAs -> three
+        //      planes through the (former u) buffer -> request the next unit
+        int fk = 0;
+        if (tile < tEnd) issue_loads(tile, 0, true);
+        while (tile < tEnd) {
+            double* const out = field_out(P, fk);
+            const bool next_new_tile = (fk + 1 == nb);
+            const int64_t nt = next_new_tile ? tile + stride : tile;
+            const int nk = next_new_tile ? 0 : fk + 1;
+            wait_vmcnt<0>();
+            double jk[ND * ND], bf[G::KSJ];
+#pragma unroll
+            for (int k = 0; k < ND * ND; ++k) jk[k] = L->j[k * G::TEL + n];
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq) {
+                const int j = 4 * jq + g;
+                bf[jq] = j < NP ? L->u[0][n * NP + (j < NP ? j : 0)] : 0.0;
+            }
+            v4d acc[NC][G::BT > 0 ? G::BT : 1];
+            double accs[NC][G::NS > 0 ? G::NS : 1];
+#pragma unroll
+            for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t) acc[r][t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) accs[r][q] = 0.0;
+            }
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bf[jq], acc[r][t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[r][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16], bf[jq],
+                                                                        accs[r][q], 0, 0, 0);
+                }
+            double* ob = L->u[0];   // every B value is in a register by now (the MFMAs consumed them)
+#pragma unroll
+            for (int x = 0; x < ND; ++x) {
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        double v = jk[x * ND] * acc[0][t][qq];
+#pragma unroll
+                        for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * acc[r][t][qq];
+                        ob[n * NP + 16 * t + g + 4 * qq] = v;
+                    }
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) {
+                    const int i = 16 * G::BT + 4 * q + g;
+                    double v = jk[x * ND] * accs[0][q];
+#pragma unroll
+                    for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * accs[r][q];
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = v;
+                }
+                wave_lds_fence();
+                double* op = out + ((int64_t)x * E + tile * G::TEL) * NP;
+                v2d held[G::SUB_INSTR];
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                                  ? *reinterpret_cast<const v2d*>(ob + 2 * qc) : v2d{0.0, 0.0};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // plane x has left the buffer
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                        __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+                wave_lds_fence();
+            }
+            if (nt < tEnd) issue_loads(nt, nk, next_new_tile);
             fk = nk;
             tile = nt;
         }
@@ -486,11 +576,11 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
 }
 
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false>
-__global__ __launch_bounds__(256, 2) void div3d_mfma_kernel(
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void div3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
     int64_t nTiles, int opT, int jes) {
-    div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
+    div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -101,16 +101,17 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
 // grad of tetrahedra p = 5 (Np = 56): grad by components with the A fragments in LDS, one block per CU
 int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
                    hipStream_t s, bool* launched) {
-    using G = fe::DivGeom<56, 1, 4, 3, true>;
+    using G = fe::DivGeom<56, 1, 4, 3, true, true>;   // eight waves per block, one block per CU
     const int64_t nTiles = E / G::TEL;
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true>, G::LDS_BYTES); });
+    const int attr_rc =
+        once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
-                       dim3(256), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
+                       dim3(G::THREADS), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
