@@ -28,7 +28,9 @@ constexpr int kFmNf = 4;   // faces of a tetrahedron (the default NF); triangles
 // ALDS: all A fragments in LDS (fragment layout) instead of registers -- tetrahedra p = 5
 // (Np = 56, Nfp = 21): 105 doubles of A per lane plus the B fragments exceed the register file.
 // One block per CU then (see DivGeom).
-template <int NP, int NFP, int M, int NF = kFmNf, bool ALDS = false>
+// W8 (with ALDS): eight waves per block share the fragments; the field slab of a unit and the output
+// transposition buffer are the same LDS and the next unit is requested after the stores (see DivGeom).
+template <int NP, int NFP, int M, int NF = kFmNf, bool ALDS = false, bool W8 = false>
 struct FmGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int K = NF * NFP;
@@ -42,12 +44,14 @@ struct FmGeom {
     static constexpr int SUB_CHUNKS = SUB_D / 2, SUB_INSTR = (SUB_CHUNKS + 63) / 64;
     static constexpr int UNIT_LOADS = NF * SLAB_INSTR;   // + J_INSTR at a tile start
     static constexpr int UNIT_STORES = M * SUB_INSTR;
+    static_assert(!W8 || (ALDS && M == 1 && UNIT_D >= SUB_D), "eight-wave blocks: A in LDS, o inside the slab buffer");
     struct WaveLds {
-        double v[2][UNIT_D];     // ring of field slabs: v[slot][f][e][j]
-        double o[SUB_D];         // output transposition buffer (one 16-element sub-tile)
+        double v[W8 ? 1 : 2][UNIT_D];   // ring of field slabs: v[slot][f][e][j]
+        double o[W8 ? 2 : SUB_D];       // output transposition buffer (one 16-element sub-tile)
         double j[NF * TEL];      // J tile, [e][f] or [f][e] as in global memory
     };
-    static constexpr int WAVES = 4;
+    static constexpr int WAVES = W8 ? 8 : 4;
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int OP_D = NF * NP * NFP;
     static constexpr int WAVE_BYTES = (int)sizeof(WaveLds) * WAVES;
     static constexpr int AFR_BIG_D = ALDS ? BT * KS * 64 : 0;      // [ks][t][lane]
@@ -60,12 +64,12 @@ struct FmGeom {
 };
 
 // UNIT_LOADS x 16-byte LDS-DMA for the field slabs (+ J_INSTR for J at a tile start).
-template <int NP, int NFP, int M, bool kWithJ, int NF = kFmNf, bool ALDS = false>
+template <int NP, int NFP, int M, bool kWithJ, int NF = kFmNf, bool ALDS = false, bool W8 = false>
 __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J,
                                                     const double* __restrict__ vk, int64_t E,
                                                     int64_t tile, int lane, unsigned lds_v,
                                                     unsigned lds_j, int jfe) {
-    using G = FmGeom<NP, NFP, M, NF, ALDS>;
+    using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     const int64_t e0 = tile * G::TEL;
     const char* vb = reinterpret_cast<const char*>(vk) + e0 * (NFP * 8) + lane * 16;
 #pragma unroll
@@ -90,11 +94,11 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 }
 
 // bid / nblk: see grad3d_mfma_body.
-template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false>
 __device__ __forceinline__ void facemass_mfma_body(
     const double* __restrict__ J, const double* __restrict__ R, const FieldPtrs& P, int64_t E,
     int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
-    using G = FmGeom<NP, NFP, M, NF, ALDS>;
+    using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,7 +117,7 @@ __device__ __forceinline__ void facemass_mfma_body(
     {
         // R goes through LDS once per block (see stage_operator)
         double* rl = reinterpret_cast<double*>(smem);
-        stage_operator<G::OP_D>(R, rl);
+        stage_operator<G::OP_D, G::THREADS>(R, rl);
         __syncthreads();
         // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i] -> strides of f, i, j
         const int sF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
@@ -133,7 +137,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 const int i = 16 * t + n;
                 const double a = rl[ridx(f, i, j)];
                 if (ALDS) {   // every wave builds the same fragments: wave w stores those of k-steps ks = w mod 4
-                    if ((ks & 3) == wave) afr[(ks * G::BT + t) * 64 + lane] = kok ? a : 0.0;
+                    if (ks % G::WAVES == wave) afr[(ks * G::BT + t) * 64 + lane] = kok ? a : 0.0;
                 } else {
                     abig[t][ks] = kok ? a : 0.0;
                 }
@@ -143,7 +147,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 const int i3 = 16 * G::BT + 4 * q + (n & 3), i3c = i3 < NP ? i3 : 0;
                 const double a3 = rl[ridx(f, i3c, j)];
                 if (ALDS) {
-                    if ((ks & 3) == wave && n < 4) afs[(ks * G::NS + q) * 16 + g * 4 + n] = (i3 < NP && kok) ? a3 : 0.0;
+                    if (ks % G::WAVES == wave && n < 4) afs[(ks * G::NS + q) * 16 + g * 4 + n] = (i3 < NP && kok) ? a3 : 0.0;
                 } else {
                     asmall[q][ks] = (i3 < NP && kok) ? a3 : 0.0;
                 }
@@ -178,9 +182,77 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
     if (first >= tEnd) return;
 
+    if constexpr (W8) {
+        // ---- eight waves per block: wait the unit -> B to registers -> MFMAs -> o through the slab
+        //      buffer -> stores -> request the next unit
+        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+        double jv8[G::KS];
+        for (int64_t tile = first; tile < tEnd; tile += stride) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                wait_vmcnt<0>();
+                if (k == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) jv8[ks] = L->j[joff[ks]];
+                }
+                double bf[G::KS];
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) bf[ks] = jv8[ks] * L->v[0][voff[ks]];
+                v4d acc[G::BT > 0 ? G::BT : 1];
+                double accs[G::NS > 0 ? G::NS : 1];
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, ks), bf[ks], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_small(q, ks), bf[ks], accs[q], 0, 0, 0);
+                }
+                double* ob = L->v[0];   // the slab is in registers (the MFMAs consumed it)
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) {
+                    const int i = 16 * G::BT + 4 * q + g;
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                }
+                wave_lds_fence();
+                double* op = P.out[k] + tile * G::TEL * NP;
+                v2d held[G::SUB_INSTR];
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                                  ? *reinterpret_cast<const v2d*>(ob + 2 * qc) : v2d{0.0, 0.0};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // o has left the buffer
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                        __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+                wave_lds_fence();
+                // ---- the next unit: the next field of this tile, or field 0 (and J) of the next tile
+                if (k + 1 < NB)
+                    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[(k + 1) % NB], E, tile, lane, lds_v0, lds_j, jfe);
+                else if (tile + stride < tEnd)
+                    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, tile + stride, lane, lds_v0, lds_j, jfe);
+            }
+        }
+        return;
+    }
+
     // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
-    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
 
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
@@ -229,10 +301,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 const int64_t tile2 = tile + stride * ((k + 2) / NB);
                 if (tile2 < tEnd) {
                     if (k2 == 0)
-                        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[k2], E, tile2, lane,
                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                     else
-                        fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS>(J, P.v[k2], E, tile2, lane,
+                        fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[k2], E, tile2, lane,
                                                                lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
                 }
             }
@@ -285,11 +357,11 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
 }
 
-template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false>
-__global__ __launch_bounds__(256, 2) void facemass_mfma_kernel(
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void facemass_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
     int64_t nTiles, int jfe, int rlayout) {
-    facemass_mfma_body<NP, NFP, M, NB, NF, ALDS>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
+    facemass_mfma_body<NP, NFP, M, NB, NF, ALDS, W8>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

@@ -314,15 +314,17 @@ int launch_matapply(const double* J, const double* D, const fe::FieldPtrs& P, in
 template <int NP, int NFP, int M, int NB, int NF = fe::kFmNf, bool ALDS = false>
 int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
-    using G = fe::FmGeom<NP, NFP, M, NF, ALDS>;
+    constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
+    using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS>, G::LDS_BYTES); });
+        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, G::LDS_BYTES); });
     if (attr_rc != FE_OK) return attr_rc;
-    unsigned grid = persistent_grid(nTiles, G::WAVES);
-    if (G::BLOCKS_PER_CU == 1 && grid > (unsigned)device_cu_count()) grid = (unsigned)device_cu_count();
-    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS>), dim3(grid), dim3(256), G::LDS_BYTES, s,
-                       J, R, P, E, nTiles, jfe, rifj);
+    int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+    const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>), dim3((unsigned)blocks), dim3(G::THREADS),
+                       G::LDS_BYTES, s, J, R, P, E, nTiles, jfe, rifj);
     return FE_OK;
 }
 
