@@ -2,28 +2,35 @@
 """
 bench.py -- GFLOP/s of the DG-wave p=4 grad einsum on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload grad|div|facemass|pipeline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload grad|div|facemass|graddiv|pipeline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one evaluation of the einsum over the rank's batch of elements
 (default workload: BASELINE.json configs[1], grad 'xre,rij,ej->xei', p = 4, 1e6
 elements per GPU, float64, synthetic uniform[0,1) inputs resident in HBM).
-Elements shard across ranks with no data-path collective (weak scaling); the
-only exchange is the all-gather of the per-shard result reductions, after the
-timed region.  Rank 0 prints ONE JSON line.
+Elements shard across ranks with no data-path collective (weak scaling by
+default; ``--elems-total`` splits one global batch instead); the only exchange
+is the all-gather of the per-shard result reductions, after the timed region.
+Rank 0 prints ONE JSON line.
 
-Measurement protocol: W untimed warm-up steps, barrier + synchronize, K timed
-steps enqueued back to back on the launch stream and bracketed by HIP events on
-that same stream (fe_time_launches of the C ABI), barrier + synchronize; the
-step time is the MAX over ranks of the host wall-clock around the timed region.
-`roofline.achieved` = algorithmic bytes per launch (grad 1192 B /
+Measurement protocol: ``setup_launches`` untimed launches (first touch of every
+page, kernel attributes, device clocks settled -- reported in the line), W
+untimed warm-up steps, barrier + synchronize, K timed steps enqueued back to
+back on the launch stream and bracketed by HIP events on that same stream
+(fe_time_launches of the C ABI), barrier + synchronize; the step time is the
+MAX over ranks of the host wall-clock around the timed region.
+``roofline.achieved`` = algorithmic bytes per launch (grad 1192 B /
 element + 29 400 B for D) / mean kernel time from the HIP events.
+``protocol_ms_per_step`` is the same launch timed with the reference's own
+protocol (5 warm-ups, batches of 5, >= 10 launches and >= 2 s;
+src/feinsum/measure.py:248-275) right after the timed region.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,9 +42,10 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 NP, NF, NFP, NFIELDS = 35, 4, 15, 4
-SETTLE_LAUNCHES = 100          # part of setup (see main)
+SETUP_LAUNCHES = 100           # untimed, before the W warm-up steps; reported as `setup_launches`
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_GFLOPS = 78_600.0    # fp64 vector = matrix
+WORKLOADS = ("grad", "div", "facemass", "graddiv", "pipeline")
 
 
 def _einsums():
@@ -68,6 +76,146 @@ def _device_inputs(expr, E, device, seed):
     return dev
 
 
+# --------------------------------------------------------------------------
+# rank logic (CPU-testable: tests/test_bench_ranks_cpu.py drives it with gloo)
+# --------------------------------------------------------------------------
+
+def rank_elements(args, info) -> int:
+    """Elements this rank evaluates: ``--elems-per-gpu`` each (weak scaling, the default), or this
+    rank's tile-aligned block of ``--elems-total`` (the last rank takes the ragged tail)."""
+    from feinsum_amd import parallel
+
+    if args.elems_total:
+        start, stop = parallel.shard_bounds(args.elems_total, info.world_size, info.rank)
+        return stop - start
+    return args.elems_per_gpu
+
+
+def timed_region(step_batch, steps: int, sync, device=None):
+    """barrier + sync | K steps | barrier + sync; returns (wall seconds, kernel seconds), both the
+    MAX over ranks.  *step_batch(n)* enqueues n steps and returns their device seconds."""
+    from feinsum_amd import parallel
+
+    sync()
+    parallel.barrier()
+    sync()
+    t0 = time.perf_counter()
+    kernel_s = step_batch(steps)
+    sync()
+    parallel.barrier()
+    sync()
+    wall_s = time.perf_counter() - t0
+    return parallel.max_over_ranks(wall_s, device), parallel.max_over_ranks(kernel_s, device)
+
+
+def exchange_results(outs, sync):
+    """The one exchange of the sharded path: every rank reduces its outputs locally
+    ([sum, sum of squares, max |.|] per output), the few doubles are all-gathered and combined.
+    Returns (combined [n_outputs, 3] tensor, local-reduction ms, all-gather ms): the first time is
+    torch reductions over this rank's own outputs, only the second is a collective."""
+    from feinsum_amd import parallel
+
+    sync()
+    t0 = time.perf_counter()
+    local = parallel.result_reduction(outs)
+    sync()
+    t1 = time.perf_counter()
+    gathered = parallel.allgather_reduction(local)
+    total = parallel.combine_reductions(gathered)
+    sync()
+    t2 = time.perf_counter()
+    return total, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+
+def compose_line(*, workload, n_gpus, steps, warmup, setup_launches=SETUP_LAUNCHES, wall_s, kernel_s, flops_step_all, flops_step_rank0,
+                 bytes_step_rank0, elems_rank0, elems_total, variant, device_name, entry_points, extra):
+    """The JSON line from measured quantities (pure)."""
+    ms_per_step = wall_s / steps * 1e3
+    value = flops_step_all / (wall_s / steps) * 1e-9            # whole job: all ranks' flops / max-over-ranks time
+    achieved_gbs = bytes_step_rank0 / (kernel_s / steps) * 1e-9
+    e_txt = f"{elems_rank0:.0e}".replace("e+0", "e").replace("e+", "e")   # 1000000 -> "1e6"
+    ai = flops_step_rank0 / bytes_step_rank0
+    roof_gflops = min(FP64_PEAK_GFLOPS, ai * HBM_PEAK_GBS)
+    names = {"grad": f"configs[1]: grad xre,rij,ej->xei p=4 (Np=35), {e_txt} elements per GPU",
+             "div": f"div xre,rij,xej->ei p=4, {e_txt} elements per GPU",
+             "facemass": f"configs[3]: face-mass ef,fij,fej->ei x4 p=4, {e_txt} elements per GPU",
+             "graddiv": f"configs[2]: div xre,rij,xej->ei + grad sharing J and D in one launch (fusion buys the launch "
+                        f"boundary only; J is fetched by both bodies), p=4, {e_txt} elements per GPU",
+             "pipeline": f"configs[4]: div + grad + face-mass x4, {e_txt} elements per GPU"}
+    line = {
+        "metric": (f"GFLOP/s on DG-wave p=4 grad einsum ({e_txt} elems per GPU, fp64); fraction of roofline in `roofline`"
+                   if workload == "grad" else f"GFLOP/s on DG-wave p=4 {workload} ({e_txt} elems per GPU, fp64)"),
+        "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": steps,
+        "warmup": warmup, "setup_launches": setup_launches, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "strong" if elems_total else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": names[workload],
+            "elements_per_gpu": elems_rank0, "elements_total": elems_total or elems_rank0 * n_gpus,
+            "parallelism": f"element-sharded x{n_gpus}, no data-path collective",
+            "variant": variant, "device": device_name, "launches_per_step": list(entry_points),
+        },
+        "per_gpu_gflops": round(value / n_gpus, 1),
+        "frac_of_min_roofline": round(value / n_gpus / roof_gflops, 4),
+        "frac_of_fp64_peak": round(value / n_gpus / FP64_PEAK_GFLOPS, 4),
+        "kernel_ms": round(kernel_s / steps * 1e3, 5),
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": int(bytes_step_rank0)},
+    }
+    line.update(extra)
+    return line
+
+
+# --------------------------------------------------------------------------
+# evidence that is not measured live: PMC counters of a committed profile
+# --------------------------------------------------------------------------
+
+def kernel_source_sha() -> str:
+    """Hash of the kernel sources the library is built from (there is no .git on the GPU box, so
+    this -- not a commit hash -- ties a committed profile to the binary that is running)."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "feinsum_amd" / "csrc").glob("*")) + [ROOT / "include" / "feinsum_hip.h"]:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(workload: str, E: int):
+    """HBM bytes per launch and MFMA utilisation from profiles/traffic_<workload>.json (rocprofv3
+    --pmc passes, tools/pmc_summary.py) -- only if that profile was taken at this element count on
+    a library built from exactly these kernel sources; otherwise (None, note)."""
+    tfile = ROOT / "profiles" / f"traffic_{workload}.json"
+    try:
+        rec = json.loads(tfile.read_text())
+    except (OSError, ValueError):
+        return None, "no committed PMC profile for this workload"
+    if int(rec.get("E", -1)) != E:
+        return None, f"committed PMC profile is for E={rec.get('E')}"
+    if rec.get("source_sha") != kernel_source_sha():
+        return None, (f"committed PMC profile was taken on kernel sources {rec.get('source_sha')}, "
+                      f"this library is {kernel_source_sha()}")
+    return rec, None
+
+
+# --------------------------------------------------------------------------
+# device state (clocks / power / temperatures) around the timed region
+# --------------------------------------------------------------------------
+
+def device_state(ordinal: int = 0):
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        import device_state as ds
+
+        return ds.sample(ordinal)
+    except Exception as exc:   # noqa: BLE001  (diagnostics only; never fails the bench)
+        return {"error": str(exc)[:200]}
+
+
+# --------------------------------------------------------------------------
+# CPU baseline (test infrastructure timed beside the GPU number; SURVEY §8d)
+# --------------------------------------------------------------------------
+
 def _cpu_share() -> int:
     """CPUs this process may actually use: min(affinity mask, cgroup quota).  Oversubscribing a
     quota-limited box is several times slower (MI355X box: quota 16 CPUs, 256 visible)."""
@@ -81,64 +229,144 @@ def _cpu_share() -> int:
     return max(1, n)
 
 
-def _cpu_baseline(workload: str, budget_s: float = 12.0):
-    """The oracle's C loop nest (optimal 2-step schedule, OpenMP) timed on the host cores."""
+def _cpu_model() -> str:
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _reference_protocol(fn, min_secs=2.0, warmups=5, batch=5, min_rounds=10, max_secs=None):
+    """Seconds per call with the timing loop of src/feinsum/measure.py:248-275 (host clock).
+    *max_secs*: stop after the batch that crosses it (bounded sample; the line says so)."""
+    for _ in range(warmups):
+        fn()
+    total, rounds = 0.0, 0
+    while rounds < min_rounds or total < min_secs:
+        t0 = time.perf_counter()
+        for _ in range(batch):
+            fn()
+        total += time.perf_counter() - t0
+        rounds += batch
+        if max_secs is not None and total >= max_secs:
+            break
+    return total / rounds, rounds
+
+
+def cpu_baseline(workload: str, budget_s: float = 8.0, full: bool = False):
+    """The oracle's C loop nests and the reference's own ground-truth evaluator on the host cores.
+
+    Headline `value`: the hoisted (optimal 2-step schedule) C nest, OpenMP over the CPU share.
+    `also`: the two stand-ins SURVEY §8(d) asks for, at E = 1e4 (BASELINE configs[0]) and E = 1e6:
+    (i) ``np.einsum(optimize="optimal")`` -- what the reference validates against
+    (src/feinsum/measure.py:149-159) -- and (ii) the trivial single-statement nest, what a CPU
+    OpenCL device runs under the identity transform of test/test_codegen.py:115-120; both with the
+    reference's timing protocol, cut short at E = 1e6 unless *full* (stated per entry)."""
     import numpy as np
 
     from oracle import c_oracle, np_oracle
 
-    lib_native = c_oracle.load(native=True)
-    lib_native.oracle_set_num_threads(_cpu_share())   # (the OpenMP runtime is already up: torch)
-    threads = int(lib_native.oracle_num_threads())
-    E = 200_000
+    lib = c_oracle.load(native=True)
+    lib.oracle_set_num_threads(_cpu_share())   # (the OpenMP runtime is already up: torch)
+    threads = int(lib.oracle_num_threads())
     rng = np.random.default_rng(0)
-    if workload in ("grad", "graddiv", "pipeline"):
-        J, D, u = rng.random((3, 3, E)), rng.random((3, NP, NP)), rng.random((E, NP))
-        out = np.empty((3, E, NP))
-        fn = lambda: lib_native.oracle_grad3d_hoisted(J, D, u, out, E, NP)  # noqa: E731
-        flops, what = 7980.0 * E, "grad"
-        check = lambda: np_oracle.max_rel_err(  # noqa: E731
-            out[:, :64], np.einsum("xre,rij,ej->xei", J[:, :, :64], D, u[:64], optimize="optimal"))
-    elif workload == "div":
-        J, D, u = rng.random((3, 3, E)), rng.random((3, NP, NP)), rng.random((3, E, NP))
-        out = np.empty((E, NP))
-        fn = lambda: lib_native.oracle_div3d_hoisted(J, D, u, out, E, NP)  # noqa: E731
-        flops, what = 7980.0 * E, "div"
-        check = lambda: np_oracle.max_rel_err(  # noqa: E731
-            out[:64], np.einsum("xre,rij,xej->ei", J[:, :, :64], D, u[:, :64], optimize="optimal"))
-    else:
-        J, R, v = rng.random((E, NF)), rng.random((NF, NP, NFP)), rng.random((NF, E, NFP))
-        out = np.empty((E, NP))
-        fn = lambda: lib_native.oracle_facemass_hoisted(J, R, v, out, E, NP, NF, NFP, 0, 0)  # noqa: E731
-        flops, what = 17040.0 / NFIELDS * E, "face-mass (one field)"
-        check = lambda: np_oracle.max_rel_err(  # noqa: E731
-            out[:64], np.einsum("ef,fij,fej->ei", J[:64], R, v[:, :64], optimize="optimal"))
+    subs = {"grad": "xre,rij,ej->xei", "div": "xre,rij,xej->ei", "facemass": "ef,fij,fej->ei"}
+    fam = workload if workload in subs else "grad"          # graddiv / pipeline: the grad einsum
+
+    def operands(E):
+        if fam == "grad":
+            return [rng.random((3, 3, E)), rng.random((3, NP, NP)), rng.random((E, NP))], np.empty((3, E, NP))
+        if fam == "div":
+            return [rng.random((3, 3, E)), rng.random((3, NP, NP)), rng.random((3, E, NP))], np.empty((E, NP))
+        return [rng.random((E, NF)), rng.random((NF, NP, NFP)), rng.random((NF, E, NFP))], np.empty((E, NP))
+
+    def c_call(kind, ops, out, E):
+        if fam == "grad":
+            return lambda: getattr(lib, f"oracle_grad3d_{kind}")(*ops, out, E, NP)
+        if fam == "div":
+            return lambda: getattr(lib, f"oracle_div3d_{kind}")(*ops, out, E, NP)
+        return lambda: getattr(lib, f"oracle_facemass_{kind}")(*ops, out, E, NP, NF, NFP, 0, 0)
+
+    flops_elem = 7980.0 if fam != "facemass" else 17040.0 / NFIELDS
+    what = {"grad": "grad", "div": "div", "facemass": "face-mass (one field)"}[fam]
+
+    # ---- headline: hoisted nest, bounded sample
+    E = 200_000
+    ops, out = operands(E)
+    fn = c_call("hoisted", ops, out, E)
     fn()
-    assert check() <= 1e-12
+    n = 64                                        # the checker: first 64 elements against np.einsum
+    if fam == "grad":
+        head, got = [ops[0][:, :, :n], ops[1], ops[2][:n]], out[:, :n]
+    elif fam == "div":
+        head, got = [ops[0][:, :, :n], ops[1], ops[2][:, :n]], out[:n]
+    else:
+        head, got = [ops[0][:n], ops[1], ops[2][:, :n]], out[:n]
+    ref = np.einsum(subs[fam], *head, optimize="optimal")
+    assert np_oracle.max_rel_err(got, ref) <= 1e-12
     t_total, reps = 0.0, 0
     while t_total < budget_s and reps < 100000:
         t0 = time.perf_counter()
         fn()
         t_total += time.perf_counter() - t0
         reps += 1
-    return {
-        "value": round(flops * reps / t_total * 1e-9, 2), "unit": "GFLOP/s", "cores": threads,
-        "kind": "port",
+    result = {
+        "value": round(flops_elem * E * reps / t_total * 1e-9, 2), "unit": "GFLOP/s", "cores": threads,
+        "kind": "port", "cpu_model": _cpu_model(),
         "sample": (f"oracle/loopnest.c {what} p=4 optimal 2-step schedule, gcc -O3 -march=native -fopenmp, "
                    f"{reps} x E={E} elements ({t_total:.1f} s) on {threads} threads "
                    f"(CPU share of this box; {os.cpu_count()} host CPUs visible)"),
+        "also": [],
     }
 
+    # ---- SURVEY §8(d) stand-ins at E = 1e4 and E = 1e6
+    for E in (10_000, 1_000_000):
+        ops, out = operands(E)
+        big = E >= 1_000_000 and not full
+        ein = lambda: np.einsum(subs[fam], *ops, optimize="optimal")   # noqa: E731
+        if big:      # ~5-8 s per call: the full protocol (15+ calls) is `--cpu-baseline full`
+            s, n = _reference_protocol(ein, warmups=1, batch=1, min_rounds=2, min_secs=0.0)
+            proto = "shortened: 1 warm-up + 2 calls (full protocol: bench.py --cpu-baseline full, profiles/r02/cpu_baseline_full.json)"
+        else:
+            s, n = _reference_protocol(ein)
+            proto = "reference protocol: 5 warm-ups, batches of 5, >= 10 calls and >= 2 s"
+        result["also"].append({"evaluator": 'np.einsum(optimize="optimal")', "E": E, "threads": "numpy/BLAS default",
+                               "gflops": round(flops_elem * E / s * 1e-9, 3), "seconds_per_call": round(s, 6),
+                               "calls": n, "protocol": proto})
+        triv = c_call("trivial", ops, out, E)
+        s, n = _reference_protocol(triv, max_secs=6.0 if big else None)
+        entry = {"evaluator": "oracle/loopnest.c trivial single-statement nest (identity transform), OpenMP", "E": E,
+                 "threads": threads, "gflops": round(flops_elem * E / s * 1e-9, 3),
+                 "seconds_per_call": round(s, 6), "calls": n,
+                 "protocol": "reference protocol" + (", stopped after 6 s" if big else "")}
+        if fam == "grad":
+            entry["executed_gflops"] = round(33075.0 * E / s * 1e-9, 2)   # test/test_loopy_utils.py:270: 33075 per element
+        result["also"].append(entry)
+    return result
+
+
+# --------------------------------------------------------------------------
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="grad", choices=["grad", "div", "facemass", "graddiv", "pipeline"])
+    ap.add_argument("--workload", default="grad", choices=WORKLOADS)
     ap.add_argument("--elems-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--elems-total", type=int, default=0,
+                    help="split ONE global batch of this many elements over the ranks (strong scaling) instead of "
+                         "--elems-per-gpu each")
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="bounded", choices=["bounded", "full"],
+                    help="full: the complete reference timing protocol for the E = 1e6 stand-ins too (~2-3 min)")
+    ap.add_argument("--no-protocol", action="store_true", help="skip the reference-protocol timing (2 s)")
+    ap.add_argument("--setup-launches", type=int, default=SETUP_LAUNCHES,
+                    help="untimed launches before the warm-up steps (reported in the line)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
     args = ap.parse_args()
@@ -156,7 +384,8 @@ def main() -> None:
     device = torch.device("cuda", info.local_rank)
     torch.cuda.set_device(device)
     q = f.DeviceQueue(device)
-    E = args.elems_per_gpu
+    E = rank_elements(args, info)
+    sync = lambda: torch.cuda.synchronize(device)   # noqa: E731
 
     exprs = _einsums()[args.workload]
     stages, out_dicts, outs_all, flops_step, bytes_step, shared = [], [], [], 0.0, 0.0, {}
@@ -176,81 +405,79 @@ def main() -> None:
     op = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse)
 
     s = q.stream_ptr
-    # setup, untimed and not counted as warm-up steps: kernel attributes, first touch of every page,
-    # device clocks up (a 5-step run right after allocation measured 12 % low otherwise)
-    for _ in range(SETTLE_LAUNCHES):
+    state_before = device_state(info.local_rank) if info.rank == 0 else None
+    # setup, untimed and not counted as warm-up steps (SETUP_LAUNCHES is reported in the line): kernel
+    # attributes, first touch of every page, device clocks settled -- a 5-step run right after
+    # allocation measured 12 % low otherwise
+    for _ in range(args.setup_launches):
         op.launch(s)
-    torch.cuda.synchronize(device)
+    sync()
     for _ in range(args.warmup):
         op.launch(s)
-    torch.cuda.synchronize(device)
-    parallel.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    if len(op.launches) == 1 and hasattr(op.launches[0], "time_batch"):
-        kernel_s = op.launches[0].time_batch(args.steps, s)    # HIP events on the launch stream
-    else:
-        kernel_s = op.time_batch(args.steps, s)                # same, through torch's event objects
-    torch.cuda.synchronize(device)
-    parallel.barrier()
-    torch.cuda.synchronize(device)
-    wall_s = time.perf_counter() - t0
-    wall_s = parallel.max_over_ranks(wall_s, device)
-    kernel_s = parallel.max_over_ranks(kernel_s, device)
 
-    # the one exchange of the sharded path: all-gather of the per-shard result reductions
-    t1 = time.perf_counter()
-    gathered = parallel.allgather_reduction(parallel.result_reduction(outs_all))
-    total = parallel.combine_reductions(gathered)
-    torch.cuda.synchronize(device)
-    allgather_ms = (time.perf_counter() - t1) * 1e3
+    def step_batch(n):
+        if len(op.launches) == 1 and hasattr(op.launches[0], "time_batch"):
+            return op.launches[0].time_batch(n, s)    # HIP events on the launch stream (fe_time_launches)
+        return op.time_batch(n, s)                    # same, through torch's event objects
+
+    wall_s, kernel_s = timed_region(step_batch, args.steps, sync, device)
+    state_after = device_state(info.local_rank) if info.rank == 0 else None
+
+    # the reference's own protocol on the same bound launch (every rank, no barrier inside)
+    protocol_ms = None
+    if not args.no_protocol:
+        dev_s, n_launch, host_s = 0.0, 0, 0.0
+        for _ in range(measure.N_WARMUP_ROUNDS):
+            op.launch(s)
+        sync()
+        while n_launch < measure.N_MIN_TIMING_ROUNDS or host_s < measure.N_MIN_SIM_SECS:
+            t0 = time.perf_counter()
+            dev_s += step_batch(measure.LAUNCHES_PER_BATCH)      # fences like evt.wait()
+            host_s += time.perf_counter() - t0
+            n_launch += measure.LAUNCHES_PER_BATCH
+        protocol_ms = {"device": dev_s / n_launch * 1e3, "host": host_s / n_launch * 1e3, "launches": n_launch}
+
+    total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
 
+    # flops of the whole job = sum over ranks (ranks may hold different element counts)
+    flops_all = flops_step
+    if info.world_size > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([flops_step], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(t)
+        flops_all = float(t.item())
+
     if info.rank == 0:
-        n = info.world_size
-        ms_per_step = wall_s / args.steps * 1e3
-        value = n * flops_step / (wall_s / args.steps) * 1e-9
-        kern_ms = kernel_s / args.steps * 1e3
-        achieved_gbs = bytes_step / (kernel_s / args.steps) * 1e-9
-        traffic = None
-        tfile = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tfile.exists():
-            try:
-                rec = json.loads(tfile.read_text())
-                if int(rec.get("E", -1)) == E:      # PMC bytes are per launch AT the profiled size
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
-        e_txt = f"{E:.0e}".replace("e+0", "e").replace("e+", "e")   # 1000000 -> "1e6"
-        ai = flops_step / bytes_step
-        roof_gflops = min(FP64_PEAK_GFLOPS, ai * HBM_PEAK_GBS)
-        line = {
-            "metric": f"GFLOP/s on DG-wave p=4 grad einsum ({e_txt} elems per GPU, fp64); fraction of roofline in `roofline`"
-                      if args.workload == "grad" else f"GFLOP/s on DG-wave p=4 {args.workload} ({e_txt} elems per GPU, fp64)",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": {"grad": f"configs[1]: grad xre,rij,ej->xei p=4 (Np=35), {e_txt} elements per GPU",
-                             "div": f"div xre,rij,xej->ei p=4, {e_txt} elements per GPU",
-                             "facemass": f"configs[3]: face-mass ef,fij,fej->ei x4 p=4, {e_txt} elements per GPU",
-                             "graddiv": f"configs[2]: div xre,rij,xej->ei + grad sharing J and D, p=4, {e_txt} elements per GPU",
-                             "pipeline": f"configs[4]: div + grad + face-mass x4, {e_txt} elements per GPU"}[args.workload],
-                "elements_per_gpu": E, "parallelism": f"element-sharded x{n}, no data-path collective",
-                "variant": args.variant, "device": q.device.name, "launches_per_step": list(op.entry_points),
-            },
-            "per_gpu_gflops": round(value / n, 1),
-            "frac_of_min_roofline": round(value / n / roof_gflops, 4),
-            "frac_of_fp64_peak": round(value / n / FP64_PEAK_GFLOPS, 4),
-            "kernel_ms": round(kern_ms, 5),
-            "result_allgather_ms": round(allgather_ms, 3), "result_finite": finite,
-            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_step)},
-        }
-        if n == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = _cpu_baseline(args.workload)
+        extra = {"result_reduction_ms": round(reduction_ms, 3), "result_allgather_ms": round(allgather_ms, 3),
+                 "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
+                 "dist_backend": info.backend if info.world_size > 1 else None}
+        if protocol_ms is not None:
+            extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)
+            extra["protocol"] = {"what": "reference timing protocol (src/feinsum/measure.py:248-275): 5 warm-ups, "
+                                         "batches of 5 launches, >= 10 launches and >= 2 s; HIP events per batch",
+                                 "launches": protocol_ms["launches"],
+                                 "host_ms_per_step": round(protocol_ms["host"], 5)}
+        extra["device_state"] = {"before": state_before, "after": state_after}
+        line = compose_line(workload=args.workload, n_gpus=info.world_size, steps=args.steps, warmup=args.warmup,
+                            setup_launches=args.setup_launches,
+                            wall_s=wall_s, kernel_s=kernel_s, flops_step_all=flops_all, flops_step_rank0=flops_step,
+                            bytes_step_rank0=bytes_step, elems_rank0=E, elems_total=args.elems_total,
+                            variant=args.variant, device_name=q.device.name, entry_points=op.entry_points,
+                            extra=extra)
+        rec, note = committed_counters(args.workload, E)
+        if rec is not None and not args.no_fuse:
+            line["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+            line["roofline"]["traffic_source"] = {k: rec.get(k) for k in ("kernel", "source_sha", "profile", "E")}
+            line["mfma_util"] = rec.get("mfma_util")
+            line["mfma_util_source"] = rec.get("mfma_util_formula")
+        else:
+            line["roofline"]["traffic_note"] = note or "PMC profile is of the fused launch"
+            line["mfma_util"] = None
+        if info.world_size == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, full=args.cpu_baseline == "full")
         print(json.dumps(line), flush=True)
 
     if info.world_size > 1:

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "fe_grad_f64", "fe_div_f64",
     "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
-    "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic",
+    "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
 )
 
 _c_double_p = C.c_void_p   # device pointers travel as plain integers
@@ -135,6 +135,8 @@ def load_library() -> C.CDLL:
     lib.fe_facemass_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_kernel_resources.restype = C.c_int
+    lib.fe_kernel_resources.argtypes = [C.c_char_p, C.c_size_t]
     lib.fe_flops_per_element.restype = C.c_int64
     lib.fe_flops_per_element.argtypes = [C.c_int32] * 5
     lib.fe_time_launches.restype = C.c_int
@@ -263,6 +265,15 @@ def facemass(J: int, R: int, v: Sequence[int], out: Sequence[int], E: int, Np: i
         raise InvalidParameterError("face-mass: need as many outputs as fields")
     check(load_library().fe_facemass_f64(J, R, _ptr_array(v), _ptr_array(out), E, Np, nf, Nfp,
                                          len(v), layout_flags, variant_code(variant), stream))
+
+
+def kernel_resources() -> str:
+    """Registers / LDS / resident blocks per CU of the kernels configured so far in this process."""
+    buf = C.create_string_buffer(1 << 16)
+    n = load_library().fe_kernel_resources(buf, len(buf))
+    if n < 0:
+        check(n)
+    return buf.value.decode()
 
 
 def flops_per_element(family: int, Np: int, nf: int = 0, Nfp: int = 0, b: int = 1) -> int:

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void einsum_generic_kernel(fe_einsum_desc d, f
                 ++sidx[k - 1];
             }
     };
-    if (d.n_sum > 0) {
+    if (d.n_sum > 0 && n_sum_points > 0) {   // (an empty summation space has zero extents: carry() would not end)
         sidx[d.n_sum - 1] = part;
         carry();
     }

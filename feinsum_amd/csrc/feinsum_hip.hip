@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "../../include/feinsum_hip.h"
 #include "fe_common.h"
@@ -54,10 +55,35 @@ int device_cu_count() {
     return cus[dev];
 }
 
+// Resources of every kernel configured so far in this process (fe_kernel_resources).
+std::mutex g_resources_mutex;
+std::string g_resources;
+
+// Once per (kernel, device): raise the dynamic-LDS limit, then check that the compiled kernel really
+// has the residency its launch geometry assumes.  The persistent grids are sized as
+// blocks_per_cu x #CUs; if a compiler change pushed the kernel over a register step (> 256 VGPRs
+// at two blocks of four waves per CU) the grid's second half would silently queue behind the
+// first and every test would still pass at half the speed.
 template <typename K>
-int set_max_lds(K kernel, int bytes) {
-    FE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+int configure_kernel(K kernel, const char* what, int lds_bytes, int threads, int blocks_per_cu) {
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    FE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    int resident = 0;
+    FE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, threads, (size_t)lds_bytes));
+    hipFuncAttributes attr;
+    FE_HIP_CHECK(hipFuncGetAttributes(&attr, fn));
+    {
+        char line[256];
+        snprintf(line, sizeof(line), "%-34s threads %4d  VGPRs %3d  scratch %4zu B  LDS %6d B dynamic + %5zu B static  "
+                 "blocks/CU %d (geometry needs %d)\n", what, threads, attr.numRegs, (size_t)attr.localSizeBytes,
+                 lds_bytes, (size_t)attr.sharedSizeBytes, resident, blocks_per_cu);
+        std::lock_guard<std::mutex> lock(g_resources_mutex);
+        g_resources += line;
+    }
+    if (resident < blocks_per_cu)
+        return fail(FE_EHIP, "%s: %d block(s) of %d threads fit a CU but the launch geometry assumes %d "
+                    "(%d VGPRs, %d B of LDS per block): the compiled kernel's register or LDS use grew",
+                    what, resident, threads, blocks_per_cu, attr.numRegs, lds_bytes);
     return FE_OK;
 }
 
@@ -107,7 +133,10 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>, G::LDS_BYTES); });
+        once.run([] {
+        return configure_kernel(fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>, "grad p5 (components, A in LDS)", G::LDS_BYTES,
+                                G::THREADS, G::BLOCKS_PER_CU);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
@@ -123,7 +152,10 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>, G::LDS_BYTES); });
+    const int attr_rc = once.run([] {
+        return configure_kernel(fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>, "div p5 (A in LDS, planes streamed)", G::LDS_BYTES, 256,
+                                G::BLOCKS_PER_CU);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
@@ -143,8 +175,8 @@ int launch_tiled(fe::TiledArgs a, hipStream_t s) {
                     (long long)lds, (long long)kTiledMaxLds);
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
-        const int rc = set_max_lds(fe::tiled_apply_kernel<8>, (int)kTiledMaxLds);
-        return rc != FE_OK ? rc : set_max_lds(fe::tiled_apply_kernel<4>, (int)kTiledMaxLds);
+        const int rc = configure_kernel(fe::tiled_apply_kernel<8>, "tiled<8>", (int)kTiledMaxLds, fe::kTiledThreads, 1);
+        return rc != FE_OK ? rc : configure_kernel(fe::tiled_apply_kernel<4>, "tiled<4>", (int)kTiledMaxLds, fe::kTiledThreads, 1);
     });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = (a.E + a.TE - 1) / a.TE;
@@ -194,15 +226,18 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, in
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
-        int rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
-        if (rc == FE_OK) rc = set_max_lds(fe::grad3d_mfma_kernel<NP, M, 0, false>, G::LDS_BYTES);
+        char what[64];
+        snprintf(what, sizeof(what), "grad Np=%d M=%d", NP, M);
+        int rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, 2);
+        snprintf(what, sizeof(what), "grad planes Np=%d M=%d", NP, M);
+        if (rc == FE_OK) rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, false>, what, G::LDS_BYTES, 256, 2);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
-            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
-            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 2>, G::LDS_BYTES);
-            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 32>, G::LDS_BYTES);
-            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 64>, G::LDS_BYTES);
-            set_max_lds(fe::grad3d_mfma_kernel<NP, M, 96>, G::LDS_BYTES);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
         return rc;
@@ -239,13 +274,15 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
-        int rc = set_max_lds(fe::div3d_mfma_kernel<NP, M, 0>, G::LDS_BYTES);
+        char what[64];
+        snprintf(what, sizeof(what), "div Np=%d M=%d", NP, M);
+        int rc = configure_kernel(fe::div3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
-            set_max_lds(fe::div3d_mfma_kernel<NP, M, 1>, G::LDS_BYTES);
-            set_max_lds(fe::div3d_mfma_kernel<NP, M, 2>, G::LDS_BYTES);
-            set_max_lds(fe::div3d_mfma_kernel<NP, M, 3>, G::LDS_BYTES);
-            set_max_lds(fe::div3d_mfma_kernel<NP, M, 8>, G::LDS_BYTES);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
         return rc;
@@ -276,7 +313,11 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>, G::LDS_BYTES); });
+        once.run([] {
+            char what[64];
+            snprintf(what, sizeof(what), "div component Np=%d M=%d", NP, M);
+            return configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+        });
     if (attr_rc != FE_OK) return attr_rc;
     fe::FieldPtrs P = {};
     P.v[0] = u;
@@ -297,7 +338,11 @@ int launch_matapply_mode(const double* J, const double* D, const fe::FieldPtrs& 
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, MODE>, G::LDS_BYTES); });
+    const int attr_rc = once.run([] {
+        char what[64];
+        snprintf(what, sizeof(what), "matapply Np=%d M=%d mode %d", NP, M, MODE);
+        return configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, MODE>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
                        G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
@@ -318,7 +363,12 @@ int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, G::LDS_BYTES); });
+        once.run([] {
+            char what[64];
+            snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d nf=%d M=%d b=%d", NP, NFP, NF, M, NB);
+            return configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, what, G::LDS_BYTES, G::THREADS,
+                                    G::BLOCKS_PER_CU);
+        });
     if (attr_rc != FE_OK) return attr_rc;
     int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
     const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
@@ -428,7 +478,11 @@ int launch_graddiv(const double* J, const double* D, const fe::GradFields& Pg, c
     *e_done_g = *e_done_d = (nTilesG > 0 || nTilesD > 0) ? E : 0;   // remainders included
     if (nTilesG == 0 && nTilesD == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::graddiv3d_mfma_kernel<NP, MG, MD>, G::LDS_BYTES); });
+    const int attr_rc = once.run([] {
+        char what[64];
+        snprintf(what, sizeof(what), "div + grad Np=%d", NP);
+        return configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
     const unsigned grid = persistent_grid(nTiles, 4);
@@ -444,7 +498,11 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
     using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
     static PerDeviceOnce once;
     const int attr_rc =
-        once.run([] { return set_max_lds(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, G::LDS_BYTES); });
+        once.run([] {
+            char what[64];
+            snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
+            return configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
+        });
     if (attr_rc != FE_OK) return attr_rc;
     int64_t nTiles = a.nTilesG > a.nTilesD ? a.nTilesG : a.nTilesD;
     if (a.nTilesF > nTiles) nTiles = a.nTilesF;
@@ -478,7 +536,11 @@ int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
     if (nTiles == 0) return FE_OK;
     static PerDeviceOnce once;
-    const int attr_rc = once.run([] { return set_max_lds(fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>, G::LDS_BYTES); });
+    const int attr_rc = once.run([] {
+        char what[64];
+        snprintf(what, sizeof(what), "triangles %s Np=%d M=%d", MODE == 4 ? "grad" : "div", NP, M);
+        return configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+    });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
                        G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
@@ -550,6 +612,14 @@ int fe_device_info(int dev, char* name, size_t name_len, double* peak_f64_gflops
         *peak_f64_gflops = mi355 ? 128.0 * p.multiProcessorCount * (p.clockRate * 1e-6) : 0.0;
     if (peak_gbps) *peak_gbps = mi355 ? 8000.0 : 0.0;
     return FE_OK;
+}
+
+int fe_kernel_resources(char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(FE_EINVAL, "fe_kernel_resources: no buffer");
+    std::lock_guard<std::mutex> lock(g_resources_mutex);
+    strncpy(buf, g_resources.c_str(), buf_len - 1);
+    buf[buf_len - 1] = 0;
+    return (int)g_resources.size();
 }
 
 int64_t fe_flops_per_element(int32_t family, int32_t Np, int32_t nf, int32_t Nfp, int32_t b) {
@@ -639,7 +709,20 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* 
         if (reinterpret_cast<uintptr_t>(J3[x]) & 7u) return fail(FE_EINVAL, "device pointers must be 8-byte aligned");
         P.j[x] = J3[x];
     }
-    if (E == 0) return FE_OK;
+    // The planes kernel is the row-permuted MFMA grad kernel (tetrahedra p = 1..4).  Whatever it does
+    // not serve -- another order, or an explicitly requested tiled / generic variant -- runs plane by
+    // plane through the div-component launcher, which has its own MFMA (p = 5), tiled and generic paths.
+    const bool planes_kernel = (Np == 35 || Np == 20 || Np == 10 || Np == 4) &&
+                               (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA);
+    if (!planes_kernel) {
+        for (int k = 0; k < b; ++k)
+            for (int x = 0; x < 3; ++x)
+                if (P.out[k][x])
+                    if (int rc = fe_divcomp3d_f64(P.j[x], D, P.u[k], P.out[k][x], E, Np, op_flags & FE_OP_TRANSPOSED,
+                                                  variant, stream))
+                        return rc;
+        return FE_OK;
+    }
     return grad_fields_launch(P, nullptr, D, b, nx, E, Np, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, variant,
                               static_cast<hipStream_t>(stream));
 }
@@ -1079,6 +1162,10 @@ int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 block(256);
     const bool f64 = d->dtype == FE_DTYPE_F64;
+    if (d->n_sum > 0 && n_sum == 0) {   // a summation index of extent 0: every output entry is an empty sum
+        FE_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_out * (f64 ? 8 : 4), s));
+        return FE_OK;
+    }
 
     // pointwise product of congruent contiguous operands: a vectorised stream
     bool pointwise = d->n_sum == 0;

@@ -408,6 +408,10 @@ def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
                 f"einsum '{einsum.get_subscripts()}' is outside the DG kernel families;"
                 " only the generic kernel is available for it")
         bound = _GenericLaunch(einsum, arg_dict, outs)
+    # byte ranges the launch reads and writes (operator.py checks them before reordering launches)
+    span = lambda t: (int(t.data_ptr()), int(t.numel()) * int(t.element_size()))   # noqa: E731
+    bound.reads = tuple(span(arg_dict[name]) for name in sorted(einsum.all_args))
+    bound.writes = tuple(span(t) for t in outs)
     return q, bound, outs
 
 

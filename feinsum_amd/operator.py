@@ -18,7 +18,10 @@ merged:
 * div + grad + face-mass of 2..4 fields (``fe_waveop3d_f64``; config 5),
 
 and everything else is enqueued stage by stage in the order given.  Results do
-not depend on the merge: a merged launch runs the same per-tile arithmetic.
+not depend on the merge: a merged launch runs the same per-tile arithmetic, and
+stages are merged only when no stage of the set -- and no stage the merge would
+move them across -- reads or overwrites what another one writes
+(``_can_share_a_launch``).
 """
 
 from __future__ import annotations
@@ -69,6 +72,39 @@ def _single_plain_group(b: Any, family: int) -> bool:
                  or (b.groups[0].b == 1 and b.plan.layout_flags == 0 and b.groups[0].ndim == 3)))
 
 
+def _overlap(a: Sequence[Tuple[int, int]], b: Sequence[Tuple[int, int]]) -> bool:
+    """Do two lists of (address, nbytes) ranges share a byte?"""
+    return any(pa < pb + nb and pb < pa + na for pa, na in a for pb, nb in b if na and nb)
+
+
+def _conflict(x: Any, y: Any) -> bool:
+    """Must launches x and y keep their order (one writes what the other reads or writes)?"""
+    return (_overlap(x.writes, y.reads) or _overlap(x.reads, y.writes) or _overlap(x.writes, y.writes))
+
+
+def _can_share_a_launch(bound: List[Any], members: List[Any]) -> bool:
+    """May *members* run as one persistent launch placed where the first of them stands?
+
+    The bodies of a fused launch run in turn with only block barriers between them (a block that
+    has finished its div tiles starts its grad tiles while other blocks are still in div), so no
+    member may read or overwrite what another member writes -- a Laplacian staged as grad followed
+    by div OF that gradient must stay two launches.  Moving the later members up to the first
+    one's position also hops them over the stages in between: none of those may conflict with a
+    member that passes it.
+    """
+    for k, x in enumerate(members):
+        if any(_conflict(x, y) for y in members[k + 1:]):
+            return False
+    pos = {id(b): k for k, b in enumerate(bound)}
+    first = min(pos[id(m)] for m in members)
+    mine = {id(m) for m in members}
+    for m in members:
+        for hopped in bound[first + 1:pos[id(m)]]:
+            if id(hopped) not in mine and _conflict(m, hopped):
+                return False
+    return True
+
+
 def _merge(bound: List[Any]) -> List[Any]:
     """Replace the first mergeable (div, grad[, face-mass]) set by its fused launch."""
     grads = [b for b in bound if _single_plain_group(b, FAMILY_GRAD)]
@@ -80,11 +116,17 @@ def _merge(bound: List[Any]) -> List[Any]:
             dp = d.groups[0]
             if (dp.J, dp.D, dp.E, dp.Np, d.variant) != (gp.J, gp.D, gp.E, gp.Np, g.variant):
                 continue
+            if not _can_share_a_launch(bound, [g, d]):
+                continue
             lift = next((m for m in bound if _single_plain_group(m, FAMILY_FACEMASS)
                          and 2 <= m.groups[0].b <= 4 and m.variant == g.variant
-                         and (m.groups[0].E, m.groups[0].Np) == (gp.E, gp.Np)), None)
+                         and (m.groups[0].E, m.groups[0].Np) == (gp.E, gp.Np)
+                         and _can_share_a_launch(bound, [g, d, m])), None)
             fused = _WaveOpLaunch(g, d, lift) if lift is not None else _GradDivLaunch(g, d)
-            gone = {id(g), id(d)} | ({id(lift)} if lift is not None else set())
+            members = [g, d] + ([lift] if lift is not None else [])
+            fused.reads = tuple(r for m in members for r in m.reads)
+            fused.writes = tuple(w for m in members for w in m.writes)
+            gone = {id(m) for m in members}
             first = min(k for k, b in enumerate(bound) if id(b) in gone)
             rest = [b for b in bound if id(b) not in gone]
             return rest[:first] + [fused] + _merge(rest[first:])

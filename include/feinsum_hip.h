@@ -214,6 +214,14 @@ int fe_facemass_f64(const double* J, const double* R,
                     int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
                     int32_t layout_flags, int32_t variant, void* stream);
 
+/* Text table of the MFMA / tiled kernels configured so far in this process, one line each:
+ * threads, VGPRs, scratch, LDS per block and the resident blocks per CU the HIP occupancy query
+ * reports next to the number the launch geometry assumes.  (A kernel is configured -- and the
+ * residency checked: FE_EHIP if it fell below what the persistent grid is sized for -- on its first
+ * launch on a device.)  Returns the full length of the table; at most buf_len - 1 characters are
+ * copied.  No reference counterpart: the reference reads such figures off loopy's generated code. */
+int fe_kernel_resources(char* buf, size_t buf_len);
+
 /* Algorithmic flops per element for a family (numerator of GFLOP/s; same
  * counter as measure.py:278-331 on the opt_einsum-optimal schedule):
  * grad/div 2*3*Np*Np + 2*9*Np; face-mass b*(nf*Nfp + 2*Np*nf*Nfp);

@@ -1,0 +1,122 @@
+"""bench.py's rank logic with world_size 2 on CPU (gloo): element split, barrier-bracketed timed
+region with MAX over ranks, the result-reduction exchange, and the JSON line built from them.
+The per-shard evaluator here is the oracle (test infrastructure); on the GPU box it is the HIP path
+-- the code under test is everything around it."""
+
+import argparse
+import json
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+
+import dg
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, elems_total, elems_per_gpu, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    import feinsum_amd as f
+    from feinsum_amd import parallel
+    from feinsum_amd.measure import generate_host_input_arrays
+    from oracle import np_oracle
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    info = parallel.init_distributed("gloo")
+    args = argparse.Namespace(elems_total=elems_total, elems_per_gpu=elems_per_gpu)
+    E = bench.rank_elements(args, info)
+    expr = dg.grad()
+    if elems_total:      # one global batch: this rank's block of the same arrays
+        host = parallel.shard_host_arrays(expr, generate_host_input_arrays(expr, elems_total), world, rank)
+    else:                # weak scaling: every rank draws its own batch
+        host = generate_host_input_arrays(expr, E, np_seed=1000 * rank)
+    assert host["u"].shape[0] == E
+    out = np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in expr.args[0]]])[0]
+
+    # a rank-dependent "kernel": rank r's batch of n steps takes 20 (r + 1) ms per step
+    def step_batch(n):
+        time.sleep(0.02 * (rank + 1) * n)
+        return 0.01 * (rank + 1) * n
+
+    wall_s, kernel_s = bench.timed_region(step_batch, 3, sync=lambda: None)
+    total, red_ms, gather_ms = bench.exchange_results([torch.from_numpy(out)], sync=lambda: None)
+    flops = float(f.count_ops(expr, long_dim_length=E))
+    t = torch.tensor([flops], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        line = bench.compose_line(workload="grad", n_gpus=world, steps=3, warmup=0, wall_s=wall_s, kernel_s=kernel_s,
+                                  flops_step_all=float(t.item()) * 1e6, flops_step_rank0=flops * 1e6,   # (x 1e6: the line rounds to 0.1 GFLOP/s)
+                                  bytes_step_rank0=8.0 * (149 * E + 3675) * 1e6, elems_rank0=E, elems_total=elems_total,
+                                  variant="auto", device_name="cpu rehearsal", entry_points=("fe_grad",),
+                                  extra={"result_reduction_ms": red_ms, "result_allgather_ms": gather_ms})
+        json.dump({"line": line, "total": total.tolist(), "wall_s": wall_s, "kernel_s": kernel_s},
+                  open(os.path.join(tmpdir, "rank0.json"), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("elems_total,elems_per_gpu", [(83, 0), (0, 40)])
+def test_two_rank_bench_logic(tmp_path, elems_total, elems_per_gpu):
+    import torch.multiprocessing as mp
+
+    from feinsum_amd.measure import generate_host_input_arrays
+    from oracle import np_oracle
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), elems_total, elems_per_gpu, str(tmp_path)), nprocs=world, join=True)
+    rec = json.load(open(tmp_path / "rank0.json"))
+    line = rec["line"]
+    # MAX over ranks: rank 1 sleeps 3 x 40 ms, rank 0 only 3 x 20 ms
+    assert 0.12 <= rec["wall_s"] < 0.5 and rec["kernel_s"] == pytest.approx(0.06)
+    expr = dg.grad()
+    if elems_total:
+        host = generate_host_input_arrays(expr, elems_total)
+        ref = np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in expr.args[0]]])[0]
+        n_all, e0 = elems_total, 32          # 83 = 32 + 51: tile-aligned block, ragged tail on the last rank
+        assert line["scaling"] == "strong"
+    else:
+        refs = []
+        for r in range(world):
+            host = generate_host_input_arrays(expr, elems_per_gpu, np_seed=1000 * r)
+            refs.append(np_oracle.reference_outputs(expr.get_subscripts(), [[host[a.name] for a in expr.args[0]]])[0])
+        ref = np.concatenate(refs, axis=1)
+        n_all, e0 = world * elems_per_gpu, elems_per_gpu
+        assert line["scaling"] == "weak"
+    np.testing.assert_allclose(rec["total"][0], [ref.sum(), (ref * ref).sum(), np.abs(ref).max()], rtol=1e-13)
+    # whole-job value = all ranks' flops / max-over-ranks step time
+    assert line["value"] == pytest.approx(7980 * n_all * 1e6 / (rec["wall_s"] / 3) * 1e-9, rel=1e-3)
+    assert line["n_gpus"] == 2 and line["config"]["elements_per_gpu"] == e0
+    assert line["config"]["elements_total"] == n_all
+    assert line["kernel_ms"] == pytest.approx(20.0)
+    assert line["roofline"]["achieved"] == pytest.approx(8.0 * (149 * e0 + 3675) * 1e6 / 0.02 * 1e-9, rel=1e-3)
+    assert {"result_reduction_ms", "result_allgather_ms", "setup_launches", "ms_per_step"} <= set(line)
+    assert line["roofline"]["traffic"] is None
+
+
+def test_committed_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    import bench
+
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: sha)
+    rec = {"E": 1000, "source_sha": sha, "hbm_bytes_per_launch": 123.0, "kernel": "k"}
+    (prof / "traffic_grad.json").write_text(json.dumps(rec))
+    assert bench.committed_counters("grad", 1000)[0]["hbm_bytes_per_launch"] == 123.0
+    assert bench.committed_counters("grad", 2000) == (None, "committed PMC profile is for E=1000")
+    (prof / "traffic_grad.json").write_text(json.dumps(dict(rec, source_sha="0" * 16)))
+    got, note = bench.committed_counters("grad", 1000)
+    assert got is None and "kernel sources" in note
+    assert bench.committed_counters("div", 1000)[0] is None

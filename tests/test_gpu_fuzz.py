@@ -32,6 +32,24 @@ def test_empty_batch_of_planes():
     assert all(tuple(o.shape) == (0, 35) for o in outs.values())
 
 
+@pytest.mark.timeout(120)
+def test_generic_einsum_with_an_empty_summation_axis():
+    """A summed index of extent 0 (the long axis summed away, E = 0): every output entry is an empty
+    sum -- zeros, and the launch returns (the kernel's odometer must not spin on a zero extent)."""
+    import torch
+
+    import feinsum_amd as f
+
+    for subs, shapes in (("ij,ej->i", [(5, 7), ("E", 7)]), ("ej,ej->j", [("E", 6), ("E", 6)]),
+                         ("eij,ej->i", [("E", 3, 4), ("E", 4)])):
+        args = [f.array(f"a{k}", s) for k, s in enumerate(shapes)]
+        expr = f.einsum(subs, *args)
+        dev = {a.name: torch.zeros(tuple(0 if d == "E" else d for d in s), dtype=torch.float64, device="cuda")
+               for a, s in zip(args, shapes)}
+        out = f.evaluate(expr, 0, dev, wait=True)["_fe_out"]
+        assert out.numel() > 0 and bool((out == 0).all())
+
+
 @pytest.mark.parametrize("variant", ["auto", "tiled", "generic"])
 def test_kernels_write_only_their_outputs(variant):
     """Outputs placed between sentinel guard bands: nothing outside the output arrays is written

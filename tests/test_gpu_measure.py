@@ -182,6 +182,37 @@ def test_wave_operator_single_launch(Np, Nfp, E):
     assert op.time_batch(2) > 0
 
 
+@pytest.mark.parametrize("E", [4099, 40_009])
+def test_laplacian_stages_keep_their_order(E):
+    """div(grad(u)): the div stage reads what the grad stage writes, so the two must not share a
+    persistent launch (its bodies run in turn without a grid barrier); results equal fuse=False
+    and the oracle."""
+    import torch
+
+    from oracle import np_oracle
+
+    grad, div = dg.grad(), dg.div()
+    host = generate_host_input_arrays(grad, E)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    grad_out = torch.zeros((3, E, 35), dtype=torch.float64, device="cuda")
+    stages = [(grad, dev), (div, {"J": dev["J"], "R": dev["R"], "u": grad_out})]
+    out_dicts = [{"_fe_out": grad_out}, None]
+    op = f.bind_operator(stages, 0, out_dicts=out_dicts)
+    assert op.entry_points == ("fe_grad", "fe_div")
+    fused = f.evaluate_operator(stages, 0, out_dicts=out_dicts, wait=True)
+    lap = fused[1]["_fe_out"].clone()
+    grad_out.zero_()
+    plain = f.evaluate_operator(stages, 0, out_dicts=out_dicts, fuse=False, wait=True)
+    assert torch.equal(lap, plain[1]["_fe_out"])
+    g_ref = np.einsum("xre,rij,ej->xei", host["J"], host["R"], host["u"], optimize="optimal")
+    ref = np.einsum("xre,rij,xej->ei", host["J"], host["R"], g_ref, optimize="optimal")
+    assert np_oracle.max_rel_err(lap.cpu().numpy(), ref) <= 1e-12
+    # independent div and grad over the same geometry still share one launch
+    other = torch.rand((3, E, 35), dtype=torch.float64, device="cuda")
+    op = f.bind_operator([(grad, dev), (div, {"J": dev["J"], "R": dev["R"], "u": other})], 0)
+    assert op.entry_points == ("fe_graddiv3d_f64",)
+
+
 def test_record_facts_measures_and_retrieve_picks_the_faster_variant(tmp_path):
     # the archive loop of examples/howto_autotune.py: record -> query -> retrieve -> timeit
     db = str(tmp_path / "facts.sqlite")

@@ -544,3 +544,109 @@ def test_full_size_wave_operator(torch_cuda):
     for a, b in zip(fused, plain):
         for k in a:
             assert torch.equal(a[k], b[k]) and bool(torch.isfinite(a[k]).all())
+
+
+# ---- sizes at which every wave walks several tiles, and BASELINE config 5's element count ----
+
+def _device_inputs(torch, expr, E, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    dev = {}
+    for arg in sorted(expr.all_args):
+        shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[arg])
+        dev[arg] = torch.rand(shape, dtype=torch.float64, device="cuda", generator=g)
+    return dev
+
+
+def _sampled_oracle_check(expr, dev, outs, E, slices):
+    from oracle import np_oracle
+
+    long_axis = [isinstance(d, f.SizeParam) for d in expr.shape].index(True)
+    for sl in slices:
+        host = {}
+        for arg, t in dev.items():
+            idx = tuple(sl if isinstance(d, f.SizeParam) else slice(None) for d in expr.arg_to_shape[arg])
+            host[arg] = t[idx].cpu().numpy()
+        ref = _oracle(expr, host)
+        for k in ref:
+            got = outs[k][(slice(None),) * long_axis + (sl,)].cpu().numpy()
+            assert np_oracle.max_rel_err(got, ref[k]) <= TOL, (k, sl)
+
+
+P5_MULTI_TILE = {
+    "grad": lambda: dg.grad(56), "grad_t": lambda: dg.grad_t(56), "batched_grad_b2": lambda: dg.batched_grad(2, 56),
+    "div": lambda: dg.div(56), "batched_div_b2": lambda: dg.batched_div(2, 56),
+    "div_components": lambda: dg.batched_div_components(56),
+    "face_mass_b4": lambda: dg.face_mass(4, Np=56, Nfp=21), "face_mass_b3_jfi": lambda: dg.face_mass_jfi_fe(3, Np=56, Nfp=21),
+    "cross_product": lambda: dg.cross_product_batch(56),
+}
+
+
+@pytest.mark.parametrize("name", sorted(P5_MULTI_TILE))
+def test_p5_every_wave_walks_several_tiles(torch_cuda, name):
+    """Np = 56 at E = 70 003: more than 16 x 8 x 256 elements, so the eight-wave blocks (one per CU)
+    loop to a second and third tile -- the path where a wave's input buffer doubles as its output
+    transposition buffer and the next tile (with a new J tile) is requested behind the stores.
+    MFMA against the generic kernels over the whole array, the oracle on head / middle / tail."""
+    torch = torch_cuda
+    E = 70_003
+    expr = P5_MULTI_TILE[name]()
+    dev = _device_inputs(torch, expr, E, seed=11)
+    outs = f.evaluate(expr, 0, dev, transform="mfma", wait=True)
+    gens = f.evaluate(expr, 0, dev, transform="generic", wait=True)
+    for k in outs:
+        assert bool(torch.isfinite(outs[k]).all())
+        assert float((outs[k] - gens[k]).abs().max() / gens[k].abs().max()) <= TOL, k
+    auto = f.evaluate(expr, 0, dev, wait=True)
+    for k in outs:
+        assert torch.equal(auto[k], outs[k])            # AUTO picks the MFMA kernels at p = 5
+    _sampled_oracle_check(expr, dev, outs, E, (slice(0, 200), slice(E // 2 - 100, E // 2 + 100), slice(E - 200, E)))
+
+
+def test_full_size_graddiv_single_launch(torch_cuda):
+    """BASELINE config 3 at its own size: div + grad sharing J and D in one launch at E = 1e6 + 5 is
+    bitwise the two separate launches; sampled oracle on both outputs."""
+    torch = torch_cuda
+    E = 1_000_000 + 5
+    exprs = [dg.div(), dg.grad()]
+    devs = [_device_inputs(torch, e, E, seed=21 + k) for k, e in enumerate(exprs)]
+    devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+    stages = list(zip(exprs, devs))
+    assert f.bind_operator(stages, 0).entry_points == ("fe_graddiv3d_f64",)
+    fused = f.evaluate_operator(stages, 0, wait=True)
+    plain = f.evaluate_operator(stages, 0, fuse=False, wait=True)
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert torch.equal(a[k], b[k])
+    for expr, dev, out in zip(exprs, devs, fused):
+        _sampled_oracle_check(expr, dev, out, E, (slice(0, 300), slice(E // 2, E // 2 + 300), slice(E - 300, E)))
+
+
+def test_config5_eight_million_elements(torch_cuda):
+    """BASELINE config 5's whole element count on ONE GPU: E = 8e6 (grad out alone is 6.7 GB; byte
+    offsets pass 2^32 in every array).  Plain grad and the div + grad + lift pipeline in one launch:
+    sampled oracle on first / middle / last slices, and the single launch bitwise equal to the three
+    separate launches.  (Sharded over 8 ranks each rank runs the 1e6 case of the tests above.)"""
+    torch = torch_cuda
+    E = 8_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~65 GB of device memory")
+    exprs = [dg.div(), dg.grad(), dg.face_mass(4)]
+    devs = [_device_inputs(torch, e, E, seed=31 + k) for k, e in enumerate(exprs)]
+    devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+    slices = (slice(0, 200), slice(E // 2 - 100, E // 2 + 100), slice(5_000_001, 5_000_201), slice(E - 200, E))
+    # plain grad
+    grad_out = f.evaluate(exprs[1], 0, devs[1], wait=True)
+    _sampled_oracle_check(exprs[1], devs[1], grad_out, E, slices)
+    # the pipeline as one launch
+    stages = list(zip(exprs, devs))
+    assert f.bind_operator(stages, 0).entry_points == ("fe_waveop3d_f64",)
+    fused = f.evaluate_operator(stages, 0, wait=True)
+    assert torch.equal(fused[1]["_fe_out"], grad_out["_fe_out"])
+    del grad_out
+    for expr, dev, out in zip(exprs, devs, fused):
+        _sampled_oracle_check(expr, dev, out, E, slices)
+    plain = f.evaluate_operator(stages, 0, fuse=False, wait=True)
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert torch.equal(a[k], b[k]) and bool(torch.isfinite(a[k]).all())

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""
+Clocks, power and temperatures of a GPU, read from sysfs (no HIP call, no subprocess):
+
+    python tools/device_state.py [ordinal]      -> one JSON line
+
+Used by bench.py (before / after the timed region) and by the profiling scripts, so that every
+measured number carries the state of the device it ran on: across the MI355X devices of the pool
+the same binary ranged 0.193-0.24 ms for the headline launch.
+
+What is read (whatever exists; missing files are skipped):
+  pp_dpm_sclk / pp_dpm_mclk / pp_dpm_fclk       current level of each clock domain (the starred row)
+  hwmon: power1_average|power1_input, power1_cap  (microwatts -> W)
+         temp*_input with temp*_label             (millidegrees -> C: edge / junction / mem)
+         freq*_input with freq*_label             (Hz -> MHz: sclk / mclk)
+  gpu_busy_percent, mem_busy_percent
+"""
+
+from __future__ import annotations
+
+import json
+import re
+import sys
+import time
+from pathlib import Path
+
+
+def _cards():
+    cards = []
+    for p in sorted(Path("/sys/class/drm").glob("card[0-9]*")):
+        if re.fullmatch(r"card\d+", p.name) and (p / "device" / "pp_dpm_sclk").exists():
+            cards.append(p / "device")
+    return cards
+
+
+def _read(p: Path):
+    try:
+        return p.read_text().strip()
+    except OSError:
+        return None
+
+
+def _current_level(text):
+    """'0: 132Mhz\\n1: 2400Mhz *' -> 2400"""
+    if not text:
+        return None
+    for ln in text.splitlines():
+        if ln.rstrip().endswith("*"):
+            m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+            return int(m.group(1)) if m else None
+    return None
+
+
+def sample(ordinal: int = 0) -> dict:
+    cards = _cards()
+    if not cards:
+        return {"error": "no amdgpu card with pp_dpm_sclk under /sys/class/drm"}
+    dev = cards[min(ordinal, len(cards) - 1)]
+    out: dict = {"t": round(time.time(), 3), "card": dev.parent.name}
+    for dom in ("sclk", "mclk", "fclk", "socclk"):
+        lvl = _current_level(_read(dev / f"pp_dpm_{dom}"))
+        if lvl is not None:
+            out[f"dpm_{dom}_mhz"] = lvl
+    for name in ("gpu_busy_percent", "mem_busy_percent"):
+        v = _read(dev / name)
+        if v is not None and v.lstrip("-").isdigit():
+            out[name] = int(v)
+    for hw in sorted((dev / "hwmon").glob("hwmon*")) if (dev / "hwmon").exists() else []:
+        for f in sorted(hw.glob("power1_*")):
+            if f.name in ("power1_average", "power1_input", "power1_cap"):
+                v = _read(f)
+                if v and v.isdigit():
+                    out[f.name + "_w"] = round(int(v) * 1e-6, 1)
+        for f in sorted(hw.glob("temp*_input")):
+            v, label = _read(f), _read(f.with_name(f.name.replace("_input", "_label")))
+            if v and v.lstrip("-").isdigit():
+                out[f"temp_{label or f.name[:-6]}_c"] = round(int(v) * 1e-3, 1)
+        for f in sorted(hw.glob("freq*_input")):
+            v, label = _read(f), _read(f.with_name(f.name.replace("_input", "_label")))
+            if v and v.isdigit():
+                out[f"freq_{label or f.name[:-6]}_mhz"] = round(int(v) * 1e-6)
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(sample(int(sys.argv[1]) if len(sys.argv) > 1 else 0)))
