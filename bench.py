@@ -202,14 +202,32 @@ def committed_counters(workload: str, E: int):
 # device state (clocks / power / temperatures) around the timed region
 # --------------------------------------------------------------------------
 
-def device_state(ordinal: int = 0):
+def device_sampler(ordinal: int = 0):
+    """tools/device_state.Sampler for HIP device *ordinal* (matched to its sysfs card by PCI address), or a
+    do-nothing stand-in: diagnostics never fail the bench."""
     sys.path.insert(0, str(ROOT / "tools"))
     try:
+        import torch
+
         import device_state as ds
 
-        return ds.sample(ordinal)
-    except Exception as exc:   # noqa: BLE001  (diagnostics only; never fails the bench)
-        return {"error": str(exc)[:200]}
+        pr = torch.cuda.get_device_properties(ordinal)
+        pci = None
+        if all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            pci = (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        return ds.Sampler(ordinal, pci)
+    except Exception as exc:   # noqa: BLE001
+        class _Null:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return None
+
+            def summary(self, _e=str(exc)[:200]):
+                return {"error": _e}
+
+        return _Null()
 
 
 # --------------------------------------------------------------------------
@@ -367,6 +385,8 @@ def main() -> None:
     ap.add_argument("--no-protocol", action="store_true", help="skip the reference-protocol timing (2 s)")
     ap.add_argument("--setup-launches", type=int, default=SETUP_LAUNCHES,
                     help="untimed launches before the warm-up steps (reported in the line)")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="rebuild the operator fragments in every launch instead of preparing them once at bind time")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
     args = ap.parse_args()
@@ -402,10 +422,13 @@ def main() -> None:
         bytes_step += measure._get_footprint_gbytes(expr, E) * 1e9
     if len(exprs) > 1:                   # J and D counted once
         bytes_step -= 8.0 * (9 * E + 3 * NP * NP)
-    op = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse)
+    # The operator matrices are constant across the steps of a time integrator: they are written once, here, in
+    # the kernels' MFMA fragment layout (fe_prepare_operator) and every launch fetches them from there.
+    op = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
+                                prepare=not args.no_prepare)
+    prepared = any(getattr(b, "_prepared", None) for b in op._stages)
 
     s = q.stream_ptr
-    state_before = device_state(info.local_rank) if info.rank == 0 else None
     # setup, untimed and not counted as warm-up steps (SETUP_LAUNCHES is reported in the line): kernel
     # attributes, first touch of every page, device clocks settled -- a 5-step run right after
     # allocation measured 12 % low otherwise
@@ -421,7 +444,6 @@ def main() -> None:
         return op.time_batch(n, s)                    # same, through torch's event objects
 
     wall_s, kernel_s = timed_region(step_batch, args.steps, sync, device)
-    state_after = device_state(info.local_rank) if info.rank == 0 else None
 
     # the reference's own protocol on the same bound launch (every rank, no barrier inside)
     protocol_ms = None
@@ -430,12 +452,33 @@ def main() -> None:
         for _ in range(measure.N_WARMUP_ROUNDS):
             op.launch(s)
         sync()
-        while n_launch < measure.N_MIN_TIMING_ROUNDS or host_s < measure.N_MIN_SIM_SECS:
-            t0 = time.perf_counter()
-            dev_s += step_batch(measure.LAUNCHES_PER_BATCH)      # fences like evt.wait()
-            host_s += time.perf_counter() - t0
-            n_launch += measure.LAUNCHES_PER_BATCH
+        # clocks / power / temperatures WHILE the launches run (the 2 s of this protocol; the K timed steps
+        # above are over in milliseconds): rank 0's device, sampled from a side thread every 20 ms
+        sampler = device_sampler(info.local_rank)
+        with sampler:
+            while n_launch < measure.N_MIN_TIMING_ROUNDS or host_s < measure.N_MIN_SIM_SECS:
+                t0 = time.perf_counter()
+                dev_s += step_batch(measure.LAUNCHES_PER_BATCH)      # fences like evt.wait()
+                host_s += time.perf_counter() - t0
+                n_launch += measure.LAUNCHES_PER_BATCH
+        device_under_load = sampler.summary()
         protocol_ms = {"device": dev_s / n_launch * 1e3, "host": host_s / n_launch * 1e3, "launches": n_launch}
+
+    # the same launch with the fragments rebuilt from the plain operator arrays in every launch (A/B, untimed region)
+    unprepared_ms = None
+    if prepared and not args.no_protocol:
+        op_plain = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
+                                          prepare=False)
+        for _ in range(args.warmup):
+            op_plain.launch(s)
+        sync()
+        if len(op_plain.launches) == 1 and hasattr(op_plain.launches[0], "time_batch"):
+            unprepared_ms = op_plain.launches[0].time_batch(args.steps, s) / args.steps * 1e3
+        else:
+            unprepared_ms = op_plain.time_batch(args.steps, s) / args.steps * 1e3
+        for _ in range(3):
+            op.launch(s)        # the outputs reduced below are those of the prepared launch
+        sync()
 
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
@@ -453,6 +496,8 @@ def main() -> None:
     if info.rank == 0:
         extra = {"result_reduction_ms": round(reduction_ms, 3), "result_allgather_ms": round(allgather_ms, 3),
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
+                 "operator_prepared": prepared,
+                 "kernel_ms_unprepared": None if unprepared_ms is None else round(unprepared_ms, 5),
                  "dist_backend": info.backend if info.world_size > 1 else None}
         if protocol_ms is not None:
             extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)
@@ -460,7 +505,7 @@ def main() -> None:
                                          "batches of 5 launches, >= 10 launches and >= 2 s; HIP events per batch",
                                  "launches": protocol_ms["launches"],
                                  "host_ms_per_step": round(protocol_ms["host"], 5)}
-        extra["device_state"] = {"before": state_before, "after": state_after}
+            extra["device_under_load"] = device_under_load
         line = compose_line(workload=args.workload, n_gpus=info.world_size, steps=args.steps, warmup=args.warmup,
                             setup_launches=args.setup_launches,
                             wall_s=wall_s, kernel_s=kernel_s, flops_step_all=flops_all, flops_step_rank0=flops_step,

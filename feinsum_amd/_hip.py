@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = (
     "fe_graddiv3d_f64", "fe_waveop3d_f64",
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
+    "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
+    "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64",
 )
 
 _c_double_p = C.c_void_p   # device pointers travel as plain integers
@@ -47,6 +49,7 @@ class ArgPack(C.Structure):
         ("layout_flags", C.c_int32), ("variant", C.c_int32),
         ("j3", C.POINTER(C.c_void_p)),
         ("ndim", C.c_int32),
+        ("prepared", C.c_void_p),
     ]
 
 
@@ -135,6 +138,23 @@ def load_library() -> C.CDLL:
     lib.fe_facemass_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_prepare_operator.restype = C.c_int
+    lib.fe_prepare_operator.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]
+    for name in ("fe_grad3d_prepared_f64", "fe_div3d_prepared_f64"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                       C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_facemass_prepared_f64.restype = C.c_int
+    lib.fe_facemass_prepared_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_graddiv3d_prepared_f64.restype = C.c_int
+    lib.fe_graddiv3d_prepared_f64.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_waveop3d_prepared_f64.restype = C.c_int
+    lib.fe_waveop3d_prepared_f64.argtypes = ([C.c_void_p] * 10 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64]
+                                             + [C.c_int32] * 6 + [C.c_void_p])
     lib.fe_kernel_resources.restype = C.c_int
     lib.fe_kernel_resources.argtypes = [C.c_char_p, C.c_size_t]
     lib.fe_flops_per_element.restype = C.c_int64
@@ -265,6 +285,16 @@ def facemass(J: int, R: int, v: Sequence[int], out: Sequence[int], E: int, Np: i
         raise InvalidParameterError("face-mass: need as many outputs as fields")
     check(load_library().fe_facemass_f64(J, R, _ptr_array(v), _ptr_array(out), E, Np, nf, Nfp,
                                          len(v), layout_flags, variant_code(variant), stream))
+
+
+PREPARED_OPERATOR_BYTES = 96 * 1024   # FE_PREPARED_OPERATOR_BYTES
+
+
+def prepare_operator(family: int, op: int, Np: int, nf: int, Nfp: int, flags: int, prepared: int,
+                     stream: int = 0) -> None:
+    """Write operator *op* in the kernels' fragment layout into the device buffer *prepared*
+    (PREPARED_OPERATOR_BYTES bytes).  NotImplementedError: this shape has no prepared form."""
+    check(load_library().fe_prepare_operator(family, op, Np, nf, Nfp, flags, prepared, stream))
 
 
 def kernel_resources() -> str:

@@ -143,6 +143,48 @@ __device__ __forceinline__ void stage_operator_dma(const double* __restrict__ g,
         glds4(gb + (N - 1) * 8 + lane * 4, lds + (N - 1) * 8);
 }
 
+// ---- prepared operators (fe_prepare_operator) -------------------------------------------------
+// An operator matrix is constant across the launches of a time-stepping code, while rebuilding its
+// MFMA A fragments in every launch is most of a launch's fixed cost (stage the matrix through LDS,
+// two block barriers, one dependent LDS gather per fragment: 5-9 us before the first tile of a
+// wave, half of a launch at E = 1e5).  A prepared operator is the same matrix written ONCE in
+// fragment layout: fragment f of lane l is double  ((f >> 1) * 64 + l) * 2 + (f & 1)  of its section,
+// so a wave fetches two fragments per 16-byte load, 1 KiB contiguous per wave-instruction (from L2
+// after the first wave of an XCD), with no LDS staging and no barrier.
+// The buffer has a fixed size (kPreparedBytes), so a kernel reading its own section can never run
+// past the allocation even when handed a buffer prepared for another shape.
+constexpr int kPrepHeaderBytes = 256;                 // magic, family, Np, nf, Nfp, flags
+constexpr int kPrepGradOff = kPrepHeaderBytes;        // grad section: <= 64 fragments (Np = 35: 63)
+constexpr int kPrepDivOff = kPrepGradOff + 32 * 1024; // div section: big-tile fragments, then the 4-row groups
+constexpr int kPrepDivSmallOff = kPrepDivOff + 32 * 1024;
+constexpr int kPrepFmOff = kPrepHeaderBytes;          // face-mass buffers hold R: big tiles, then 4-row groups
+constexpr int kPreparedBytes = 96 * 1024;
+constexpr unsigned long long kPrepMagic = 0x6665707265703031ull;   // "feprep01"
+
+// `count` fragments of this lane from a prepared section; set(f, value) receives them.  Plain loads:
+// the caller makes the compiler's own wait explicit (prepared_fragments_landed) before its main loop.
+template <int COUNT, class F>
+__device__ __forceinline__ void load_prepared_fragments(const void* section, int lane, F set) {
+    const v2d* pp = reinterpret_cast<const v2d*>(section) + lane;
+#pragma unroll
+    for (int p = 0; p < (COUNT + 1) / 2; ++p) {
+        const v2d v = pp[p * 64];
+        set(2 * p, v[0]);
+        if (2 * p + 1 < COUNT) set(2 * p + 1, v[1]);
+    }
+}
+// s_waitcnt vmcnt(0) THROUGH THE COMPILER (it models this builtin, unlike the inline-asm waits of the
+// main loops): afterwards it knows the fragment loads have landed and inserts no wait of its own
+// inside the loop -- a compiler-placed vmcnt(0) there would drain the prefetches and the stores of
+// every iteration.  (The LDS-DMA loads of the first tiles, issued behind the fragment loads, are
+// waited for too; the first iteration needs them anyway.)
+__device__ __forceinline__ void prepared_fragments_landed() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+}
+__device__ __forceinline__ void store_prepared_fragment(void* section, int f, int lane, double v) {
+    reinterpret_cast<double*>(section)[((f >> 1) * 64 + lane) * 2 + (f & 1)] = v;
+}
+
 // Tried and rejected for balancing ACROSS CUs (a few CUs finish ~10 % late): tile tickets from
 // global atomic counters.  One counter retires only ~88 atomics/us (the kernels consume ~300
 // tiles/us); eight per-XCD counters with the ticket taken one or two iterations ahead still

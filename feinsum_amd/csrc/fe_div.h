@@ -93,10 +93,15 @@ struct DivGeom {
 };
 
 // kDbg: experiment flags (0 in the product build): 1 skip MFMAs, 2 skip stores, 8 skip loads.
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
+// kPrep (register-resident fragments only): the A fragments come from a prepared operator (`prep` =
+// the whole prepared buffer, see fe_common.h) -- the big-tile fragments by coalesced loads straight
+// into registers, the 4-row groups copied as they are into their LDS table; D is still needed by the
+// remainder code.
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __device__ __forceinline__ void div3d_mfma_body(
-    const double* __restrict__ J, const double* __restrict__ D, const FieldPtrs& P, int nb, int64_t E,
-    int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
+    const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, const FieldPtrs& P,
+    int nb, int64_t E, int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
+    static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,7 +117,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     double abig[(G::BT > 0 && !ALDS) ? G::BT : 1][ALDS ? 1 : G::KSJ][ALDS ? 1 : NC];
     double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - (G::ASMALL_D + G::ABIG_D) * 8));
     double* afr = asmall + G::ASMALL_D;   // ALDS: big-tile fragments [(jq * NC + r) * BT + t][lane]
-    {
+    if constexpr (!kPrep) {
         double* dl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D, G::THREADS>(D, dl);
         __syncthreads();
@@ -384,7 +389,32 @@ __device__ __forceinline__ void div3d_mfma_body(
         return;
     }
     bool first = true;
-    if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+    if constexpr (kPrep) {
+        // fragments from the prepared operator; the first tile streams in meanwhile (no staging area to wait for)
+        const char* pb = reinterpret_cast<const char*>(prep);
+        constexpr int BT1 = G::BT > 0 ? G::BT : 1;   // (no 16-row tiles below Np = 16: no fragments either)
+        load_prepared_fragments<G::BT * G::KSJ * NC>(pb + kPrepDivOff, lane, [&](int f, double v) {
+            abig[f % BT1][(f / BT1) / NC][(f / BT1) % NC] = v;      // f = (jq NC + r) BT + t
+        });
+        const double* ps = reinterpret_cast<const double*>(pb + kPrepDivSmallOff);
+        constexpr int kPer = (G::ASMALL_D + G::THREADS - 1) / G::THREADS;
+        double held[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = threadIdx.x + k * G::THREADS;
+            held[k] = idx < G::ASMALL_D ? ps[idx] : 0.0;
+        }
+        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+        prepared_fragments_landed();
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = threadIdx.x + k * G::THREADS;
+            if (idx < G::ASMALL_D) asmall[idx] = held[k];
+        }
+        __syncthreads();   // the table of the 4-row groups is complete
+    } else {
+        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+    }
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
     while (tile < tEnd) {
@@ -576,11 +606,39 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
 }
 
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void div3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E,
-    int64_t nTiles, int opT, int jes) {
-    div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8>(J, D, P, nb, E, nTiles, opT, jes, blockIdx.x, gridDim.x);
+    const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, FieldPtrs P, int nb,
+    int64_t E, int64_t nTiles, int opT, int jes) {
+    div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8, kPrep>(J, D, prep, P, nb, E, nTiles, opT, jes, blockIdx.x,
+                                                            gridDim.x);
+}
+
+// The div sections of a prepared operator (plain div of tetrahedra): big-tile fragment
+// f = (jq NC + r) BT + t of lane (g, n) is D'[row 16 t + n][k = (jq, r), j = 4 jq + g], and the table
+// of the 4-row groups exactly as the prologue above lays it out in LDS.  Blocks 0 .. FRAGS-1 write one
+// fragment each, the blocks behind them 64 table entries each.
+template <int NP, int M>
+__global__ __launch_bounds__(64) void div_prepare_kernel(const double* __restrict__ D, void* __restrict__ prepared,
+                                                         int opT) {
+    using G = DivGeom<NP, M>;
+    constexpr int NC = G::NC, FRAGS = G::BT * G::KSJ * NC;
+    char* pb = reinterpret_cast<char*>(prepared);
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;
+    if ((int)blockIdx.x < FRAGS) {
+        constexpr int BT1 = G::BT > 0 ? G::BT : 1;
+        const int f = blockIdx.x, t = f % BT1, jq = (f / BT1) / NC, r = (f / BT1) % NC;
+        const int j = 4 * jq + g, i = 16 * t + n;
+        store_prepared_fragment(pb + kPrepDivOff, f, lane, j < NP ? D[r * (NP * NP) + i * istride + j * jstride] : 0.0);
+        return;
+    }
+    const int idx = ((int)blockIdx.x - FRAGS) * 64 + lane;
+    if (idx >= G::ASMALL_D) return;
+    const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
+    const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
+    reinterpret_cast<double*>(pb + kPrepDivSmallOff)[idx] =
+        (j < NP && i < NP) ? D[r * (NP * NP) + i * istride + j * jstride] : 0.0;
 }
 
 }  // namespace fe

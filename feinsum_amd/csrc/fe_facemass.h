@@ -94,10 +94,14 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 }
 
 // bid / nblk: see grad3d_mfma_body.
-template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false>
+// kPrep (register-resident fragments only): the A fragments come from a prepared operator (`prep` =
+// the whole prepared buffer: fragments ks BT + t of the 16-row tiles, then BT KS + ks NS + q of the
+// 4-row groups); no LDS staging and no block barrier.  R itself is still needed by the remainder code.
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __device__ __forceinline__ void facemass_mfma_body(
-    const double* __restrict__ J, const double* __restrict__ R, const FieldPtrs& P, int64_t E,
-    int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
+    const double* __restrict__ J, const double* __restrict__ R, const void* __restrict__ prep, const FieldPtrs& P,
+    int64_t E, int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
+    static_assert(!kPrep || !ALDS, "prepared operators: fragments in registers");
     using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
@@ -114,7 +118,20 @@ __device__ __forceinline__ void facemass_mfma_body(
     double asmall[(G::NS > 0 && !ALDS) ? G::NS : 1][ALDS ? 1 : G::KS]; // 4x4x4_4b group q: block n/4, row 16 BT + 4q + n%4, k = g
     double* afr = reinterpret_cast<double*>(smem + (G::LDS_BYTES - G::AFR_D * 8));   // ALDS: big tiles [ks][t][lane] ...
     double* afs = afr + G::AFR_BIG_D;                                                //       ... small groups [ks][q][g][row]
-    {
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {   // k = 4 ks + g; padded k-steps read a valid (finite) B value against A = 0
+        const int kk = 4 * ks + g, k = kk < G::K ? kk : 0;
+        const int f = k / NFP, j = k - f * NFP;
+        voff[ks] = f * G::SLAB_D + n * NFP + j;
+        joff[ks] = jfe ? f * G::TEL + n : n * NF + f;
+    }
+    if constexpr (kPrep) {
+        load_prepared_fragments<(G::BT + G::NS) * G::KS>(reinterpret_cast<const char*>(prep) + kPrepFmOff, lane,
+                                                       [&](int f, double v) {
+            if (f < G::BT * G::KS) abig[f % (G::BT > 0 ? G::BT : 1)][f / (G::BT > 0 ? G::BT : 1)] = v;
+            else asmall[(f - G::BT * G::KS) % (G::NS > 0 ? G::NS : 1)][(f - G::BT * G::KS) / (G::NS > 0 ? G::NS : 1)] = v;
+        });
+    } else {
         // R goes through LDS once per block (see stage_operator)
         double* rl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D, G::THREADS>(R, rl);
@@ -130,8 +147,6 @@ __device__ __forceinline__ void facemass_mfma_body(
             const bool kok = kk < G::K;            // NF NFP need not be a multiple of 4: padded k-steps
             const int k = kok ? kk : 0;            // read a valid (finite) B value, multiply it by A = 0
             const int f = k / NFP, j = k - f * NFP;
-            voff[ks] = f * G::SLAB_D + n * NFP + j;
-            joff[ks] = jfe ? f * G::TEL + n : n * NF + f;
 #pragma unroll
             for (int t = 0; t < G::BT; ++t) {
                 const int i = 16 * t + n;
@@ -253,6 +268,7 @@ __device__ __forceinline__ void facemass_mfma_body(
     // prologue: units 0 and 1 of the first tile
     fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
     fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
+    if constexpr (kPrep) prepared_fragments_landed();
 
     int slot = 0;
     bool warm = false;   // false for the first two units of this wave
@@ -357,11 +373,36 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
 }
 
-template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void facemass_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E,
-    int64_t nTiles, int jfe, int rlayout) {
-    facemass_mfma_body<NP, NFP, M, NB, NF, ALDS, W8>(J, R, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x);
+    const double* __restrict__ J, const double* __restrict__ R, const void* __restrict__ prep, FieldPtrs P,
+    int64_t E, int64_t nTiles, int jfe, int rlayout) {
+    facemass_mfma_body<NP, NFP, M, NB, NF, ALDS, W8, kPrep>(J, R, prep, P, E, nTiles, jfe, rlayout, blockIdx.x,
+                                                            gridDim.x);
+}
+
+// The face-mass section of a prepared operator: one block of 64 threads per fragment (layout: see
+// facemass_mfma_body, kPrep); the values are those the staging prologue builds.
+template <int NP, int NFP, int M, int NF = kFmNf>
+__global__ __launch_bounds__(64) void facemass_prepare_kernel(const double* __restrict__ R, void* __restrict__ prepared,
+                                                              int rlayout) {
+    using G = FmGeom<NP, NFP, M, NF>;
+    const int fr = blockIdx.x, lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    if (fr >= (G::BT + G::NS) * G::KS) return;
+    const int sF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
+    const int sI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
+    const int sJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : NF * NP;
+    const bool big = fr < G::BT * G::KS;
+    const int ks = big ? fr / (G::BT > 0 ? G::BT : 1) : (fr - G::BT * G::KS) / (G::NS > 0 ? G::NS : 1);
+    const int kk = 4 * ks + g;
+    const bool kok = kk < G::K;
+    const int k = kok ? kk : 0, f = k / NFP, j = k - f * NFP;
+    int i;
+    if (big) i = 16 * (fr % (G::BT > 0 ? G::BT : 1)) + n;
+    else i = 16 * G::BT + 4 * ((fr - G::BT * G::KS) % (G::NS > 0 ? G::NS : 1)) + (n & 3);
+    const bool ok = kok && i < NP;
+    store_prepared_fragment(reinterpret_cast<char*>(prepared) + kPrepFmOff, fr, lane,
+                            ok ? R[f * sF + i * sI + j * sJ] : 0.0);
 }
 
 }  // namespace fe

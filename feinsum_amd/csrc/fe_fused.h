@@ -33,13 +33,15 @@ struct GradDivGeom {
     static constexpr int LDS_BYTES = cmax<GradGeom<NP, MG>::LDS_BYTES, DivGeom<NP, MD>::LDS_BYTES>();
 };
 
-template <int NP, int MG, int MD>
+// kPrep: both bodies take their A fragments from the prepared operator `prep` (fe_prepare_operator).
+template <int NP, int MG, int MD, bool kPrep = false>
 __global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, GradFields Pg, FieldPtrs Pd,
-    int64_t E, int64_t nTilesG, int64_t nTilesD, int opT) {
-    div3d_mfma_body<NP, MD>(J, D, Pd, 1, E, nTilesD, opT, 0, blockIdx.x, gridDim.x);
+    const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, GradFields Pg,
+    FieldPtrs Pd, int64_t E, int64_t nTilesG, int64_t nTilesD, int opT) {
+    div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, opT, 0, blockIdx.x, gridDim.x);
     body_boundary();
-    grad3d_mfma_body<NP, MG>(Pg, D, 1, 3, E, nTilesG, opT, blockIdx.x, gridDim.x);
+    grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, reinterpret_cast<const char*>(prep) + kPrepGradOff, 1, 3, E,
+                                             nTilesG, opT, blockIdx.x, gridDim.x);
 }
 
 // div, grad and lift (face-mass x NB) of one time-step stage.
@@ -54,19 +56,23 @@ struct WaveOpArgs {
     const double* D;     // [3][Np][Np]
     const double* Jf;    // face-mass J
     const double* R;     // face-mass operator
+    const void* prepD;   // prepared D (grad and div sections) and prepared R, or null
+    const void* prepR;
     int64_t E, nTilesG, nTilesD, nTilesF;
     int jfe, rlayout;
 };
 
-template <int NP, int NFP, int MG, int MD, int MF, int NB>
+template <int NP, int NFP, int MG, int MD, int MF, int NB, bool kPrep = false>
 __global__ __launch_bounds__(256, 2) void waveop3d_mfma_kernel(WaveOpArgs a, GradFields Pg, FieldPtrs Pd,
                                                                FieldPtrs Pf) {
-    div3d_mfma_body<NP, MD>(a.J, a.D, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x, gridDim.x);
+    div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
+                                                          gridDim.x);
     body_boundary();
-    grad3d_mfma_body<NP, MG>(Pg, a.D, 1, 3, a.E, a.nTilesG, 0, blockIdx.x, gridDim.x);
+    grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, reinterpret_cast<const char*>(a.prepD) + kPrepGradOff, 1, 3, a.E,
+                                             a.nTilesG, 0, blockIdx.x, gridDim.x);
     body_boundary();
-    facemass_mfma_body<NP, NFP, MF, NB>(a.Jf, a.R, Pf, a.E, a.nTilesF, a.jfe, a.rlayout, blockIdx.x,
-                                        gridDim.x);
+    facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe,
+                                                                    a.rlayout, blockIdx.x, gridDim.x);
 }
 
 }  // namespace fe

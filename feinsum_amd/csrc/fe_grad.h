@@ -196,10 +196,13 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 // the wave walks (tile, field) units, field fastest.
 // bid / nblk: this block's index and the number of blocks walking the tiles (blockIdx.x /
 // gridDim.x for the plain kernel; the fused launches of fe_fused.h run several bodies in turn).
-template <int NP, int M, int kDbg = 0, bool kPlain = true>
+// kPrep: the A fragments come from a prepared operator (fe_prepare_operator; `prep` = its grad
+// section) instead of being rebuilt from D: no LDS staging, no block barrier -- the waves of a block
+// never meet.  D itself is still needed by the remainder code.
+template <int NP, int M, int kDbg = 0, bool kPlain = true, bool kPrep = false>
 __device__ __forceinline__ void grad3d_mfma_body(
-    const GradFields& P, const double* __restrict__ D, int nb, int nx_, int64_t E, int64_t nTiles, int opT,
-    const unsigned bid, const unsigned nblk) {
+    const GradFields& P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx_, int64_t E,
+    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk) {
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -217,33 +220,43 @@ __device__ __forceinline__ void grad3d_mfma_body(
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     int64_t tile = (int64_t)bid * G::WAVES + wave;
 
-    // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
-    stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
+    double afrag[G::RT][G::KS];
     bool pre = false;   // unit 1 already requested
-    if (tile < tEnd && !(kDbg & 8)) {
+    // the loads of this wave's first two units (behind the operator copy / the fragment loads)
+    auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
+        if (!(tile < tEnd) || (kDbg & 8)) return 0;
         grad_issue_u<NP, M, kNT>(P.u[0], tile, lane, lds_addr_uniform(L->u[0]));
         grad_issue_j<NP, M, kPlain>(P, E, tile, lane, lds_addr_uniform(L->j[0]));
         if (nb > 1) {
             grad_issue_u<NP, M, kNT>(P.u[1], tile, lane, lds_addr_uniform(L->u[1]));
             pre = true;
-            wait_vmcnt<G::LOADS + G::U_INSTR>();
-        } else if (tile + stride < tEnd) {
+            return 1;
+        }
+        if (tile + stride < tEnd) {
             grad_issue_u<NP, M, kNT>(P.u[0], tile + stride, lane, lds_addr_uniform(L->u[1]));
             grad_issue_j<NP, M, kPlain>(P, E, tile + stride, lane, lds_addr_uniform(L->j[1]));
             pre = true;
-            wait_vmcnt<2 * G::LOADS>();
-        } else {
-            wait_vmcnt<G::LOADS>();
+            return 2;
         }
+        return 3;
+    };
+    if constexpr (kPrep) {
+        load_prepared_fragments<G::RT * G::KS>(prep, lane, [&](int f, double v) { afrag[f / G::KS][f % G::KS] = v; });
+        issue_first_units();
+        prepared_fragments_landed();
     } else {
-        wait_vmcnt<0>();
-    }
-    __syncthreads();
+        // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
+        stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
+        switch (issue_first_units()) {
+            case 1: wait_vmcnt<G::LOADS + G::U_INSTR>(); break;
+            case 2: wait_vmcnt<2 * G::LOADS>(); break;
+            case 3: wait_vmcnt<G::LOADS>(); break;
+            default: wait_vmcnt<0>(); break;
+        }
+        __syncthreads();
 
-    // ---- A fragments from the staged operator (addresses = row part + column part: the 63
-    //      fragments of p = 4 cost one add and one LDS read each)
-    double afrag[G::RT][G::KS];
-    {
+        // ---- A fragments from the staged operator (addresses = row part + column part: the 63
+        //      fragments of p = 4 cost one add and one LDS read each)
         const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
         const int gp = n & 3, q = n >> 2;
         const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
@@ -406,11 +419,29 @@ __device__ __forceinline__ void grad3d_mfma_body(
 #endif
 }
 
-template <int NP, int M, int kDbg = 0, bool kPlain = true>
+template <int NP, int M, int kDbg = 0, bool kPlain = true, bool kPrep = false>
 __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
-    GradFields P, const double* __restrict__ D, int nb, int nx, int64_t E, int64_t nTiles, int opT) {
-    grad3d_mfma_body<NP, M, kDbg, kPlain>(P, D, nb, nx, E, nTiles, opT, blockIdx.x, gridDim.x);
+    GradFields P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx, int64_t E,
+    int64_t nTiles, int opT) {
+    grad3d_mfma_body<NP, M, kDbg, kPlain, kPrep>(P, D, prep, nb, nx, E, nTiles, opT, blockIdx.x, gridDim.x);
 }
 
+// The grad section of a prepared operator: fragment f = t * KS + ks of lane (g, n) is
+// A[row slot 4 t + n / 4 of lane group n % 4][k = 4 ks + g] -- the value the prologue above builds.
+// One block of 64 threads per fragment.
+template <int NP, int M>
+__global__ __launch_bounds__(64) void grad_prepare_kernel(const double* __restrict__ D, void* __restrict__ section,
+                                                          int opT) {
+    using G = GradGeom<NP, M>;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f >= G::RT * G::KS) return;
+    const int t = f / G::KS, ks = f % G::KS;
+    const int n = lane & 15, g = lane >> 4;
+    const int gp = n & 3, q = n >> 2;
+    const int s = 4 * t + q, r = s % 3, i = G::TG * gp + s / 3, j = 4 * ks + g;
+    const bool ok = (s < 3 * G::TG) && (i < NP) && (j < NP);
+    const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;
+    store_prepared_fragment(section, f, lane, ok ? D[r * (NP * NP) + i * istride + j * jstride] : 0.0);
+}
 
 }  // namespace fe

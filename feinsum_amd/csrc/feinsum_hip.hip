@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/feinsum_hip.h"
 #include "fe_common.h"
@@ -140,7 +141,7 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
-                       dim3(G::THREADS), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+                       dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -159,7 +160,7 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
-                       dim3(256), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+                       dim3(256), G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -218,7 +219,7 @@ fe::TiledArgs tiled_args(int family, const double* J, const double* A, const fe:
 }
 
 template <int NP, int M>
-int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, int nx, int64_t E,
+int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void* prep, int nb, int nx, int64_t E,
                 int dbg, int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::GradGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
@@ -229,6 +230,8 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, in
         char what[64];
         snprintf(what, sizeof(what), "grad Np=%d M=%d", NP, M);
         int rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, 2);
+        snprintf(what, sizeof(what), "grad Np=%d M=%d, prepared operator", NP, M);
+        if (rc == FE_OK) rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, true, true>, what, G::LDS_BYTES, 256, 2);
         snprintf(what, sizeof(what), "grad planes Np=%d M=%d", NP, M);
         if (rc == FE_OK) rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, false>, what, G::LDS_BYTES, 256, 2);
 #ifdef FE_EXPERIMENTS
@@ -238,35 +241,47 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, int nb, in
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
         return rc;
     });
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
+    const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
     if (!plain) {   // general planes: per-plane geometry-factor and output pointers
-        hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, false>), g, b, G::LDS_BYTES, s, P, D, nb, nx, E, nTiles,
-                           opT);
+        hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, false>), g, b, G::LDS_BYTES, s, P, D, nullptr, nb, nx, E,
+                           nTiles, opT);
         return FE_OK;
     }
 #define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, P, D, nb, nx, E, nTiles, opT)
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, P, D, nullptr, nb, nx, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
         case 2: FE_GRAD_CASE(2); break;
-        case 32: FE_GRAD_CASE(32); break;
+        case 32:
+            if (gsec)
+                hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
+                                   E, nTiles, opT);
+            else FE_GRAD_CASE(32);
+            break;
         case 64: FE_GRAD_CASE(64); break;
         case 96: FE_GRAD_CASE(96); break;
 #endif
-        default: FE_GRAD_CASE(0); break;
+        default:
+            if (gsec)
+                hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
+                                   E, nTiles, opT);
+            else FE_GRAD_CASE(0);
+            break;
     }
 #undef FE_GRAD_CASE
     return FE_OK;
 }
 
 template <int NP, int M>
-int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int dbg,
+int launch_div(const double* J, const double* D, const void* prep, const fe::FieldPtrs& P, int nb, int64_t E, int dbg,
                int opT, hipStream_t s, int64_t* e_done) {
     using G = fe::DivGeom<NP, M>;
     const int64_t nTiles = E / G::TEL;
@@ -277,6 +292,10 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
         char what[64];
         snprintf(what, sizeof(what), "div Np=%d M=%d", NP, M);
         int rc = configure_kernel(fe::div3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+        snprintf(what, sizeof(what), "div Np=%d M=%d, prepared operator", NP, M);
+        if (rc == FE_OK)
+            rc = configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, 0, 3, false, false, true>, what, G::LDS_BYTES, 256,
+                                  G::BLOCKS_PER_CU);
 #ifdef FE_EXPERIMENTS
         if (NP == 35) {
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
@@ -290,7 +309,7 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_DIV_CASE(DBG) \
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0)
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_DIV_CASE(1); break;
@@ -298,7 +317,12 @@ int launch_div(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
         case 3: FE_DIV_CASE(3); break;
         case 8: FE_DIV_CASE(8); break;
 #endif
-        default: FE_DIV_CASE(0); break;
+        default:
+            if (prep)
+                hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 0, 3, false, false, true>), g, b, G::LDS_BYTES, s, J, D,
+                                   prep, P, nb, E, nTiles, opT, 0);
+            else FE_DIV_CASE(0);
+            break;
     }
 #undef FE_DIV_CASE
     return FE_OK;
@@ -324,8 +348,8 @@ int launch_divcomp(const double* J, const double* D, const double* u, double* ou
     P.out[0] = out;
     unsigned grid = persistent_grid(nTiles, G::WAVES);
     if (G::BLOCKS_PER_CU == 1 && grid > (unsigned)device_cu_count()) grid = (unsigned)device_cu_count();
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, P,
-                       1, E, nTiles, opT, jes);
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 1, 3, ALDS>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D,
+                       nullptr, P, 1, E, nTiles, opT, jes);
     return FE_OK;
 }
 
@@ -345,7 +369,7 @@ int launch_matapply_mode(const double* J, const double* D, const fe::FieldPtrs& 
     });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
-                       G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+                       G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -357,43 +381,57 @@ int launch_matapply(const double* J, const double* D, const fe::FieldPtrs& P, in
 }
 
 template <int NP, int NFP, int M, int NB, int NF = fe::kFmNf, bool ALDS = false>
-int launch_fm_nb(const double* J, const double* R, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
+int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::FieldPtrs& P, int64_t E, int64_t nTiles,
                  int jfe, int rifj, hipStream_t s) {
     constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
+    constexpr bool kCanPrep = !ALDS && NF == fe::kFmNf;   // prepared operators: tetrahedra p = 1..4
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
     static PerDeviceOnce once;
-    const int attr_rc =
-        once.run([] {
-            char what[64];
-            snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d nf=%d M=%d b=%d", NP, NFP, NF, M, NB);
-            return configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, what, G::LDS_BYTES, G::THREADS,
-                                    G::BLOCKS_PER_CU);
-        });
+    const int attr_rc = once.run([] {
+        char what[80];
+        snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d nf=%d M=%d b=%d", NP, NFP, NF, M, NB);
+        int rc = configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, what, G::LDS_BYTES, G::THREADS,
+                                  G::BLOCKS_PER_CU);
+        if constexpr (kCanPrep) {
+            snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d M=%d b=%d, prepared operator", NP, NFP, M, NB);
+            if (rc == FE_OK)
+                rc = configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>, what, G::LDS_BYTES,
+                                      G::THREADS, G::BLOCKS_PER_CU);
+        }
+        return rc;
+    });
     if (attr_rc != FE_OK) return attr_rc;
     int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
     const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
     if (blocks > cap) blocks = cap;
+    if constexpr (kCanPrep) {
+        if (prep) {
+            hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>), dim3((unsigned)blocks),
+                               dim3(G::THREADS), G::LDS_BYTES, s, J, R, prep, P, E, nTiles, jfe, rifj);
+            return FE_OK;
+        }
+    }
     hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>), dim3((unsigned)blocks), dim3(G::THREADS),
-                       G::LDS_BYTES, s, J, R, P, E, nTiles, jfe, rifj);
+                       G::LDS_BYTES, s, J, R, nullptr, P, E, nTiles, jfe, rifj);
     return FE_OK;
 }
 
 // One MFMA launch for a group of nb fields (2 <= nb <= kMaxGroup of the geometry).
 template <int NP, int NFP, int M, int NF = fe::kFmNf, bool ALDS = false>
-int launch_fm(const double* J, const double* R, const fe::FieldPtrs& P, int nb, int64_t E, int64_t nTiles,
-              int jfe, int rifj, hipStream_t s) {
+int launch_fm(const double* J, const double* R, const void* prep, const fe::FieldPtrs& P, int nb, int64_t E,
+              int64_t nTiles, int jfe, int rifj, hipStream_t s) {
     switch (nb) {
-        case 2: return launch_fm_nb<NP, NFP, M, 2, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 3: return launch_fm_nb<NP, NFP, M, 3, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
-        case 4: return launch_fm_nb<NP, NFP, M, 4, NF, ALDS>(J, R, P, E, nTiles, jfe, rifj, s);
+        case 2: return launch_fm_nb<NP, NFP, M, 2, NF, ALDS>(J, R, prep, P, E, nTiles, jfe, rifj, s);
+        case 3: return launch_fm_nb<NP, NFP, M, 3, NF, ALDS>(J, R, prep, P, E, nTiles, jfe, rifj, s);
+        case 4: return launch_fm_nb<NP, NFP, M, 4, NF, ALDS>(J, R, prep, P, E, nTiles, jfe, rifj, s);
         default: break;
     }
     if constexpr (NP == 35 && NF == fe::kFmNf) {   // p = 4, the headline order: groups of up to 8 fields
         switch (nb) {
-            case 5: return launch_fm_nb<NP, NFP, M, 5>(J, R, P, E, nTiles, jfe, rifj, s);
-            case 6: return launch_fm_nb<NP, NFP, M, 6>(J, R, P, E, nTiles, jfe, rifj, s);
-            case 7: return launch_fm_nb<NP, NFP, M, 7>(J, R, P, E, nTiles, jfe, rifj, s);
-            case 8: return launch_fm_nb<NP, NFP, M, 8>(J, R, P, E, nTiles, jfe, rifj, s);
+            case 5: return launch_fm_nb<NP, NFP, M, 5>(J, R, prep, P, E, nTiles, jfe, rifj, s);
+            case 6: return launch_fm_nb<NP, NFP, M, 6>(J, R, prep, P, E, nTiles, jfe, rifj, s);
+            case 7: return launch_fm_nb<NP, NFP, M, 7>(J, R, prep, P, E, nTiles, jfe, rifj, s);
+            case 8: return launch_fm_nb<NP, NFP, M, 8>(J, R, prep, P, E, nTiles, jfe, rifj, s);
             default: break;
         }
     }
@@ -414,7 +452,7 @@ fe::GradFields grad_fields(const double* J, const double* const* u, double* cons
 
 // MFMA launch over the full tiles + generic kernels for the rest.  Jfull != nullptr: the planes
 // are those of a plain grad (one [3][3][E] array, [3][E][Np] outputs).
-int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const double* D, int nb, int nx,
+int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const double* D, const void* prep, int nb, int nx,
                        int64_t E, int Np, int opT, int variant, hipStream_t s) {
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4 || (Np == 56 && Jfull);
     fe::FieldPtrs Pt = {};
@@ -442,10 +480,10 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_grad<35, 1>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_grad<20, 2>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_grad<10, 3>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_grad<4, 5>(P, Jfull != nullptr, D, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_grad<35, 1>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_grad<20, 2>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_grad<10, 3>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_grad<4, 5>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
@@ -469,8 +507,8 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
 
 // div then grad in one persistent launch (full tiles only; e_done_* report what was covered)
 template <int NP, int MG, int MD>
-int launch_graddiv(const double* J, const double* D, const fe::GradFields& Pg, const fe::FieldPtrs& Pd,
-                   int64_t E, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
+int launch_graddiv(const double* J, const double* D, const void* prep, const fe::GradFields& Pg,
+                   const fe::FieldPtrs& Pd, int64_t E, hipStream_t s, int64_t* e_done_g, int64_t* e_done_d) {
     using GG = fe::GradGeom<NP, MG>;
     using GD = fe::DivGeom<NP, MD>;
     using G = fe::GradDivGeom<NP, MG, MD>;
@@ -481,13 +519,20 @@ int launch_graddiv(const double* J, const double* D, const fe::GradFields& Pg, c
     const int attr_rc = once.run([] {
         char what[64];
         snprintf(what, sizeof(what), "div + grad Np=%d", NP);
-        return configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+        int rc = configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+        snprintf(what, sizeof(what), "div + grad Np=%d, prepared operator", NP);
+        if (rc == FE_OK) rc = configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD, true>, what, G::LDS_BYTES, 256, 2);
+        return rc;
     });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
     const unsigned grid = persistent_grid(nTiles, 4);
-    hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, Pg,
-                       Pd, E, nTilesG, nTilesD, 0);
+    if (prep)
+        hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD, true>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, prep,
+                           Pg, Pd, E, nTilesG, nTilesD, 0);
+    else
+        hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr,
+                           Pg, Pd, E, nTilesG, nTilesD, 0);
     return FE_OK;
 }
 
@@ -497,17 +542,24 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
                      const fe::FieldPtrs& Pf, hipStream_t s) {
     using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
     static PerDeviceOnce once;
-    const int attr_rc =
-        once.run([] {
-            char what[64];
-            snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
-            return configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
-        });
+    const int attr_rc = once.run([] {
+        char what[80];
+        snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
+        int rc = configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
+        snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d, prepared operators", NP, NB);
+        if (rc == FE_OK)
+            rc = configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>, what, G::LDS_BYTES, 256, 2);
+        return rc;
+    });
     if (attr_rc != FE_OK) return attr_rc;
     int64_t nTiles = a.nTilesG > a.nTilesD ? a.nTilesG : a.nTilesD;
     if (a.nTilesF > nTiles) nTiles = a.nTilesF;
-    hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>), dim3(persistent_grid(nTiles, 4)),
-                       dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
+    if (a.prepD && a.prepR)
+        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>), dim3(persistent_grid(nTiles, 4)),
+                           dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
+    else
+        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>), dim3(persistent_grid(nTiles, 4)),
+                           dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
     return FE_OK;
 }
 
@@ -543,7 +595,7 @@ int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
-                       G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, 0);
+                       G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -557,6 +609,59 @@ int launch_nd2_np(const double* J, const double* D, const fe::FieldPtrs& P, int 
         case 6: return launch_nd2<6, 8, MODE>(J, D, P, nb, E, opT, s, launched);
         default: return launch_nd2<3, 8, MODE>(J, D, P, nb, E, opT, s, launched);
     }
+}
+
+// ---- prepared operators: what fe_prepare_operator wrote where (host-side record, so that a launcher
+// can refuse a buffer prepared for another shape without reading device memory)
+struct PreparedInfo { int kind, Np, nf, Nfp, flags; };
+std::mutex g_prepared_mutex;
+std::unordered_map<const void*, PreparedInfo> g_prepared;
+
+// null: not usable (with *err set when the caller passed a buffer that does not fit the call)
+const void* usable_prepared(const void* prepared, int kind, int Np, int nf, int Nfp, int flags, const char* what,
+                            int* err) {
+    *err = FE_OK;
+    if (!prepared) return nullptr;
+    PreparedInfo info;
+    {
+        std::lock_guard<std::mutex> lock(g_prepared_mutex);
+        auto it = g_prepared.find(prepared);
+        if (it == g_prepared.end()) {
+            *err = fail(FE_EINVAL, "%s: the prepared-operator buffer %p was not written by fe_prepare_operator in this "
+                        "process", what, prepared);
+            return nullptr;
+        }
+        info = it->second;
+    }
+    if (info.kind != kind || info.Np != Np || info.nf != nf || info.Nfp != Nfp || info.flags != flags) {
+        *err = fail(FE_EINVAL, "%s: the prepared operator is for another call (kind %d Np %d nf %d Nfp %d flags %d; "
+                    "this call: kind %d Np %d nf %d Nfp %d flags %d)", what, info.kind, info.Np, info.nf, info.Nfp,
+                    info.flags, kind, Np, nf, Nfp, flags);
+        return nullptr;
+    }
+    return prepared;
+}
+constexpr int kPreparedD = 1, kPreparedR = 2;   // D[3][Np][Np] (grad + div sections) / face-mass R
+
+template <int NP, int MG, int MD>
+void prepare_d(const double* D, void* prepared, int opT, hipStream_t s) {
+    using GG = fe::GradGeom<NP, MG>;
+    using GD = fe::DivGeom<NP, MD>;
+    static_assert(fe::kPrepGradOff + ((GG::RT * GG::KS + 1) / 2) * 1024 <= fe::kPrepDivOff, "grad section");
+    static_assert(fe::kPrepDivOff + ((GD::BT * GD::KSJ * GD::NC + 1) / 2) * 1024 <= fe::kPrepDivSmallOff, "div section");
+    static_assert(fe::kPrepDivSmallOff + GD::ASMALL_D * 8 <= fe::kPreparedBytes, "div 4-row groups");
+    hipLaunchKernelGGL((fe::grad_prepare_kernel<NP, MG>), dim3(GG::RT * GG::KS), dim3(64), 0, s, D, 
+                       static_cast<char*>(prepared) + fe::kPrepGradOff, opT);
+    hipLaunchKernelGGL((fe::div_prepare_kernel<NP, MD>), dim3(GD::BT * GD::KSJ * GD::NC + (GD::ASMALL_D + 63) / 64),
+                       dim3(64), 0, s, D, prepared, opT);
+}
+
+template <int NP, int NFP, int M>
+void prepare_r(const double* R, void* prepared, int rlayout, hipStream_t s) {
+    using G = fe::FmGeom<NP, NFP, M>;
+    static_assert(fe::kPrepFmOff + (((G::BT + G::NS) * G::KS + 1) / 2) * 1024 <= fe::kPreparedBytes, "face-mass section");
+    hipLaunchKernelGGL((fe::facemass_prepare_kernel<NP, NFP, M>), dim3((G::BT + G::NS) * G::KS), dim3(64), 0, s, R,
+                       prepared, rlayout);
 }
 
 struct FmChoice { int max_group, tel; };
@@ -614,6 +719,45 @@ int fe_device_info(int dev, char* name, size_t name_len, double* peak_f64_gflops
     return FE_OK;
 }
 
+int fe_prepare_operator(int32_t family, const double* op, int32_t Np, int32_t nf, int32_t Nfp, int32_t flags,
+                        void* prepared, void* stream) {
+    if (!op || !prepared) return fail(FE_EINVAL, "prepare: null pointer");
+    if ((reinterpret_cast<uintptr_t>(op) & 7u) || (reinterpret_cast<uintptr_t>(prepared) & 15u))
+        return fail(FE_EINVAL, "prepare: the operator must be 8-byte and the prepared buffer 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PreparedInfo info{0, Np, 0, 0, flags};
+    if (family == FE_FAMILY_GRAD || family == FE_FAMILY_DIV || family == FE_FAMILY_GRADDIV) {
+        if (flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "prepare: bad operator flags %d", flags);
+        const int opT = (flags & FE_OP_TRANSPOSED) ? 1 : 0;
+        info.kind = kPreparedD;
+        switch (Np) {   // the (Np, M) geometries of launch_grad / launch_div
+            case 35: prepare_d<35, 1, 1>(op, prepared, opT, s); break;
+            case 20: prepare_d<20, 2, 1>(op, prepared, opT, s); break;
+            case 10: prepare_d<10, 3, 3>(op, prepared, opT, s); break;
+            case 4: prepare_d<4, 5, 5>(op, prepared, opT, s); break;
+            default: return fail(FE_EUNSUPPORTED, "prepare: grad / div operators of tetrahedra p = 1..4 only (Np=%d)", Np);
+        }
+    } else if (family == FE_FAMILY_FACEMASS) {
+        if (flags & ~(FE_FM_R_IFJ | FE_FM_R_T)) return fail(FE_EINVAL, "prepare: bad face-mass operator flags %d", flags);
+        const int rlayout = ((flags & FE_FM_R_IFJ) ? 1 : 0) + ((flags & FE_FM_R_T) ? 2 : 0);
+        info.kind = kPreparedR;
+        info.nf = nf;
+        info.Nfp = Nfp;
+        if (nf != fe::kFmNf) return fail(FE_EUNSUPPORTED, "prepare: face-mass operators of tetrahedra only (nf=%d)", nf);
+        if (Np == 35 && Nfp == 15) prepare_r<35, 15, 1>(op, prepared, rlayout, s);
+        else if (Np == 20 && Nfp == 10) prepare_r<20, 10, 1>(op, prepared, rlayout, s);
+        else if (Np == 10 && Nfp == 6) prepare_r<10, 6, 2>(op, prepared, rlayout, s);
+        else if (Np == 4 && Nfp == 3) prepare_r<4, 3, 4>(op, prepared, rlayout, s);
+        else return fail(FE_EUNSUPPORTED, "prepare: face-mass operators of tetrahedra p = 1..4 only (Np=%d Nfp=%d)", Np, Nfp);
+    } else {
+        return fail(FE_EUNSUPPORTED, "prepare: family %d has no prepared form", family);
+    }
+    FE_HIP_CHECK(hipGetLastError());
+    std::lock_guard<std::mutex> lock(g_prepared_mutex);
+    g_prepared[prepared] = info;
+    return FE_OK;
+}
+
 int fe_kernel_resources(char* buf, size_t buf_len) {
     if (!buf || buf_len == 0) return fail(FE_EINVAL, "fe_kernel_resources: no buffer");
     std::lock_guard<std::mutex> lock(g_resources_mutex);
@@ -649,13 +793,23 @@ int fe_grad3d_f64_ex(const double* J, const double* D, const double* u, double* 
 int fe_grad3d_batched_f64(const double* J, const double* D, const double* const* u,
                           double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                           int32_t variant, void* stream) {
+    return fe_grad3d_prepared_f64(J, D, nullptr, u, out, E, Np, b, op_flags, variant, stream);
+}
+
+int fe_grad3d_prepared_f64(const double* J, const double* D, const void* D_prepared, const double* const* u,
+                           double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                           int32_t variant, void* stream) {
     if (!u || !out) return fail(FE_EINVAL, "grad: null pointer table");
     if (b < 1) return fail(FE_EINVAL, "grad: b=%d, need at least one field", b);
     if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
-        if (int rc = fe_grad3d_batched_f64(J, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
-        return fe_grad3d_batched_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
-                    variant, stream);
+        if (int rc = fe_grad3d_prepared_f64(J, D, D_prepared, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream))
+            return rc;
+        return fe_grad3d_prepared_f64(J, D, D_prepared, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS,
+                                      op_flags, variant, stream);
     }
+    int perr;
+    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, op_flags, "grad", &perr);
+    if (perr != FE_OK) return perr;
     for (int k = 0; k < b; ++k)
         if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "grad: bad operator flags %d", op_flags);
@@ -667,7 +821,7 @@ int fe_grad3d_batched_f64(const double* J, const double* D, const double* const*
 #endif
         return fail(FE_EUNSUPPORTED, "grad: unknown variant %d", variant);
     if (E == 0) return FE_OK;
-    return grad_fields_launch(grad_fields(J, u, out, b, E, Np), J, D, b, 3, E, Np, opT, variant,
+    return grad_fields_launch(grad_fields(J, u, out, b, E, Np), J, D, prep, b, 3, E, Np, opT, variant,
                               static_cast<hipStream_t>(stream));
 }
 
@@ -723,7 +877,7 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* 
                         return rc;
         return FE_OK;
     }
-    return grad_fields_launch(P, nullptr, D, b, nx, E, Np, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, variant,
+    return grad_fields_launch(P, nullptr, D, nullptr, b, nx, E, Np, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, variant,
                               static_cast<hipStream_t>(stream));
 }
 
@@ -740,13 +894,23 @@ int fe_div3d_f64_ex(const double* J, const double* D, const double* u, double* o
 int fe_div3d_batched_f64(const double* J, const double* D, const double* const* u,
                          double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
                          int32_t variant, void* stream) {
+    return fe_div3d_prepared_f64(J, D, nullptr, u, out, E, Np, b, op_flags, variant, stream);
+}
+
+int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepared, const double* const* u,
+                          double* const* out, int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                          int32_t variant, void* stream) {
     if (!u || !out) return fail(FE_EINVAL, "div: null pointer table");
     if (b < 1) return fail(FE_EINVAL, "div: b=%d, need at least one field", b);
     if (b > FE_MAX_FIELDS) {   // FE_MAX_FIELDS fields per launch
-        if (int rc = fe_div3d_batched_f64(J, D, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream)) return rc;
-        return fe_div3d_batched_f64(J, D, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS, op_flags,
-                    variant, stream);
+        if (int rc = fe_div3d_prepared_f64(J, D, D_prepared, u, out, E, Np, FE_MAX_FIELDS, op_flags, variant, stream))
+            return rc;
+        return fe_div3d_prepared_f64(J, D, D_prepared, u + FE_MAX_FIELDS, out + FE_MAX_FIELDS, E, Np, b - FE_MAX_FIELDS,
+                                     op_flags, variant, stream);
     }
+    int perr;
+    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, op_flags, "div", &perr);
+    if (perr != FE_OK) return perr;
     fe::FieldPtrs P = {};
     for (int k = 0; k < b; ++k) {
         if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
@@ -783,10 +947,10 @@ int fe_div3d_batched_f64(const double* J, const double* D, const double* const* 
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_div<35, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_div<20, 1>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_div<10, 3>(J, D, P, b, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_div<4, 5>(J, D, P, b, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
+            case 20: rc = launch_div<20, 1>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
+            case 10: rc = launch_div<10, 3>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
+            default: rc = launch_div<4, 5>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }
@@ -940,6 +1104,15 @@ int fe_matapply_f64(const double* J, const double* D, const double* const* u, do
 int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, const double* v_div,
                      double* grad_out, double* div_out, int64_t E, int32_t Np, int32_t variant,
                      void* stream) {
+    return fe_graddiv3d_prepared_f64(J, D, nullptr, u_grad, v_div, grad_out, div_out, E, Np, variant, stream);
+}
+
+int fe_graddiv3d_prepared_f64(const double* J, const double* D, const void* D_prepared, const double* u_grad,
+                              const double* v_div, double* grad_out, double* div_out, int64_t E, int32_t Np,
+                              int32_t variant, void* stream) {
+    int perr;
+    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, 0, "graddiv", &perr);
+    if (perr != FE_OK) return perr;
     if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
     if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
     if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
@@ -947,8 +1120,8 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
     const bool mfma_ok = Np == 35 || Np == 20 || Np == 10 || Np == 4;
     if ((variant != FE_VARIANT_AUTO && variant != FE_VARIANT_MFMA) || !mfma_ok) {
         // two launches back to back on the stream
-        if (int rc = fe_div3d_f64(J, D, v_div, div_out, E, Np, variant, stream)) return rc;
-        return fe_grad3d_f64(J, D, u_grad, grad_out, E, Np, variant, stream);
+        if (int rc = fe_div3d_prepared_f64(J, D, D_prepared, &v_div, &div_out, E, Np, 1, 0, variant, stream)) return rc;
+        return fe_grad3d_prepared_f64(J, D, D_prepared, &u_grad, &grad_out, E, Np, 1, 0, variant, stream);
     }
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -958,10 +1131,10 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
     int64_t done_g = 0, done_d = 0;
     int rc = FE_OK;
     switch (Np) {   // same (Np, M) geometries as the separate launches
-        case 35: rc = launch_graddiv<35, 1, 1>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
-        case 20: rc = launch_graddiv<20, 2, 1>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
-        case 10: rc = launch_graddiv<10, 3, 3>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
-        default: rc = launch_graddiv<4, 5, 5>(J, D, Pg, Pd, E, s, &done_g, &done_d); break;
+        case 35: rc = launch_graddiv<35, 1, 1>(J, D, prep, Pg, Pd, E, s, &done_g, &done_d); break;
+        case 20: rc = launch_graddiv<20, 2, 1>(J, D, prep, Pg, Pd, E, s, &done_g, &done_d); break;
+        case 10: rc = launch_graddiv<10, 3, 3>(J, D, prep, Pg, Pd, E, s, &done_g, &done_d); break;
+        default: rc = launch_graddiv<4, 5, 5>(J, D, prep, Pg, Pd, E, s, &done_g, &done_d); break;
     }
     if (rc != FE_OK) return rc;
     if (done_d < E)
@@ -977,6 +1150,15 @@ int fe_graddiv3d_f64(const double* J, const double* D, const double* u_grad, con
 int fe_facemass_f64(const double* J, const double* R, const double* const* v, double* const* out,
                     int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
                     int32_t layout_flags, int32_t variant, void* stream) {
+    return fe_facemass_prepared_f64(J, R, nullptr, v, out, E, Np, nf, Nfp, b, layout_flags, variant, stream);
+}
+
+int fe_facemass_prepared_f64(const double* J, const double* R, const void* R_prepared, const double* const* v,
+                             double* const* out, int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                             int32_t layout_flags, int32_t variant, void* stream) {
+    int perr;   // (the J layout flag is not part of the operator)
+    const void* prep = usable_prepared(R_prepared, kPreparedR, Np, nf, Nfp, layout_flags & ~FE_FM_J_FE, "face-mass", &perr);
+    if (perr != FE_OK) return perr;
     if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
     if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
         return fail(FE_EINVAL, "face-mass: Np, nf, Nfp, b must be positive (%d %d %d %d)", Np, nf,
@@ -1044,19 +1226,19 @@ int fe_facemass_f64(const double* J, const double* R, const double* const* v, do
             int rc = FE_OK;
             if (nf == 3) {
                 switch (Np) {   // triangles; wave tile = 16 M elements
-                    case 21: rc = launch_fm<21, 6, 3, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 15: rc = launch_fm<15, 5, 4, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 10: rc = launch_fm<10, 4, 5, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 6: rc = launch_fm<6, 3, 6, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    default: rc = launch_fm<3, 2, 8, 3>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 21: rc = launch_fm<21, 6, 3, 3>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 15: rc = launch_fm<15, 5, 4, 3>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 10: rc = launch_fm<10, 4, 5, 3>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 6: rc = launch_fm<6, 3, 6, 3>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    default: rc = launch_fm<3, 2, 8, 3>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
                 }
             } else {
                 switch (Np) {   // tetrahedra
-                    case 56: rc = launch_fm<56, 21, 1, fe::kFmNf, true>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 35: rc = launch_fm<35, 15, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 20: rc = launch_fm<20, 10, 1>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    case 10: rc = launch_fm<10, 6, 2>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
-                    default: rc = launch_fm<4, 3, 4>(J, R, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 56: rc = launch_fm<56, 21, 1, fe::kFmNf, true>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 35: rc = launch_fm<35, 15, 1>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 20: rc = launch_fm<20, 10, 1>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    case 10: rc = launch_fm<10, 6, 2>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
+                    default: rc = launch_fm<4, 3, 4>(J, R, prep, P, nb, E, nTiles, jfe, rifj, s); break;
                 }
             }
             if (rc != FE_OK) return rc;
@@ -1084,13 +1266,28 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
                     const double* v_div, double* div_out, const double* Jface, const double* R,
                     const double* const* f, double* const* lift, int64_t E, int32_t Np, int32_t nf,
                     int32_t Nfp, int32_t b, int32_t fm_layout_flags, int32_t variant, void* stream) {
+    return fe_waveop3d_prepared_f64(J, D, nullptr, u_grad, grad_out, v_div, div_out, Jface, R, nullptr, f, lift, E, Np, nf,
+                                    Nfp, b, fm_layout_flags, variant, stream);
+}
+
+int fe_waveop3d_prepared_f64(const double* J, const double* D, const void* D_prepared, const double* u_grad,
+                             double* grad_out, const double* v_div, double* div_out, const double* Jface,
+                             const double* R, const void* R_prepared, const double* const* f, double* const* lift,
+                             int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b, int32_t fm_layout_flags,
+                             int32_t variant, void* stream) {
+    int perr;
+    const void* prepD = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, 0, "waveop", &perr);
+    if (perr != FE_OK) return perr;
+    const void* prepR = usable_prepared(R_prepared, kPreparedR, Np, nf, Nfp, fm_layout_flags & ~FE_FM_J_FE, "waveop", &perr);
+    if (perr != FE_OK) return perr;
     FmChoice geo{0, 16};
     const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && nf == fe::kFmNf && Np != 56 &&
                        fm_mfma_geometry(Np, nf, Nfp, &geo) && b >= 2 &&
                        b <= 4 && f && lift && E > 0 && !(fm_layout_flags & ~7);
     if (!fused) {   // three launches (argument checks included)
-        if (int rc = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc;
-        return fe_facemass_f64(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream);
+        if (int rc = fe_graddiv3d_prepared_f64(J, D, D_prepared, u_grad, v_div, grad_out, div_out, E, Np, variant, stream))
+            return rc;
+        return fe_facemass_prepared_f64(Jface, R, R_prepared, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream);
     }
     if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
     if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
@@ -1113,6 +1310,7 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
     }
     fe::WaveOpArgs a = {};
     a.J = J; a.D = D; a.Jf = Jface; a.R = R; a.E = E;
+    a.prepD = prepD; a.prepR = prepR;
     a.jfe = (fm_layout_flags & FE_FM_J_FE) ? 1 : 0;
     a.rlayout = ((fm_layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((fm_layout_flags & FE_FM_R_T) ? 2 : 0);
     bool launched = false;
@@ -1128,6 +1326,7 @@ int fe_waveop3d_f64(const double* J, const double* D, const double* u_grad, doub
         if (int rc2 = fe_graddiv3d_f64(J, D, u_grad, v_div, grad_out, div_out, E, Np, variant, stream)) return rc2;
         return fe_facemass_f64(Jface, R, f, lift, E, Np, nf, Nfp, b, fm_layout_flags, variant, stream);
     }
+    (void)prepD; (void)prepR;
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
@@ -1233,16 +1432,18 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
             if (a->ndim == 2)
                 return fe_grad_f64(a->J, a->D, a->v, a->outs, a->E, 2, a->Np, a->b, a->layout_flags, a->variant, stream);
             if (a->b > 1)
-                return fe_grad3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
-                                             a->variant, stream);
-            return fe_grad3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
+                return fe_grad3d_prepared_f64(a->J, a->D, a->prepared, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
+                                              a->variant, stream);
+            return fe_grad3d_prepared_f64(a->J, a->D, a->prepared, &a->u, &a->out, a->E, a->Np, 1, a->layout_flags,
+                                          a->variant, stream);
         case FE_FAMILY_DIV:
             if (a->ndim == 2)
                 return fe_div_f64(a->J, a->D, a->v, a->outs, a->E, 2, a->Np, a->b, a->layout_flags, a->variant, stream);
             if (a->b > 1)
-                return fe_div3d_batched_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
-                                            a->variant, stream);
-            return fe_div3d_f64_ex(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
+                return fe_div3d_prepared_f64(a->J, a->D, a->prepared, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
+                                             a->variant, stream);
+            return fe_div3d_prepared_f64(a->J, a->D, a->prepared, &a->u, &a->out, a->E, a->Np, 1, a->layout_flags,
+                                         a->variant, stream);
         case FE_FAMILY_GRADPLANES:
             return fe_gradplanes3d_f64(a->j3, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags,
                                        a->variant, stream);
@@ -1250,13 +1451,13 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
             return fe_matapply_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->b, a->layout_flags, a->variant,
                                    stream);
         case FE_FAMILY_GRADDIV:
-            return fe_graddiv3d_f64(a->J, a->D, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
-                                    a->variant, stream);
+            return fe_graddiv3d_prepared_f64(a->J, a->D, a->prepared, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
+                                             a->variant, stream);
         case FE_FAMILY_DIVCOMP:
             return fe_divcomp3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
         case FE_FAMILY_FACEMASS:
-            return fe_facemass_f64(a->J, a->D, a->v, a->outs, a->E, a->Np, a->nf, a->Nfp, a->b,
-                                   a->layout_flags, a->variant, stream);
+            return fe_facemass_prepared_f64(a->J, a->D, a->prepared, a->v, a->outs, a->E, a->Np, a->nf, a->Nfp, a->b,
+                                            a->layout_flags, a->variant, stream);
         default: return fail(FE_EINVAL, "unknown family %d", family);
     }
 }

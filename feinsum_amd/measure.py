@@ -22,7 +22,9 @@ Argument conventions kept from the reference:
                exist in this build, so a callable (or ``None``) is ignored and
                selects the default kernel variant, while a ``str`` / ``dict``
                (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
-               a variant explicitly.
+               a variant explicitly; ``{"prepared": False}`` makes a bound
+               launch (``timeit``, ``bind_operator``) rebuild its operator
+               fragments in every launch instead of using a prepared copy.
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -117,6 +119,13 @@ def _variant_from_transform(transform: Any):
     if isinstance(transform, Mapping):
         return transform.get("variant")
     return transform
+
+
+def _prepared_from_transform(transform: Any, default: bool) -> bool:
+    """``{"prepared": False}`` in a transform dict turns prepared operators off for a bound launch."""
+    if isinstance(transform, Mapping) and "prepared" in transform:
+        return bool(transform["prepared"])
+    return default
 
 
 # --------------------------------------------------------------------------
@@ -223,6 +232,7 @@ class _FamilyLaunch:
         long_axis = einsum.in_idx_sets[role[long_role]].index(plan.long_index)
         self.E = int(arg_dict[first[role[long_role]].name].shape[long_axis])
         self._keep = (arg_dict, outs)
+        self._prepared: Dict[Any, Any] = {}   # (operator pointer, flags) -> prepared device buffer
         p = plan.params
         op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_MATAPPLY) else "R"
         self.groups = []   # list of ArgPack (one per launch)
@@ -253,6 +263,38 @@ class _FamilyLaunch:
             pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
             self.groups.append(pack)
             k = k2
+
+    def prepare_operators(self, stream_ptr: int = 0) -> int:
+        """Write the operator of every launch group that has a prepared form (grad / div / face-mass of
+        tetrahedra p = 1..4, ``fe_prepare_operator``) into a device buffer owned by this bound launch;
+        the launches then fetch their MFMA fragments from it instead of rebuilding them from the
+        plain array every time.  The buffers are SNAPSHOTS: call this again after changing an
+        operator array in place.  Returns the number of prepared groups."""
+        import torch
+
+        if self.variant not in (_hip.VARIANT_AUTO, _hip.VARIANT_MFMA) or self.group_family == FAMILY_GRADPLANES \
+                or self.plan.family not in (FAMILY_GRAD, FAMILY_DIV, FAMILY_FACEMASS):
+            return 0
+        done = 0
+        for pack in self.groups:
+            if self.plan.family != FAMILY_FACEMASS and pack.ndim != 3:
+                continue
+            key = (pack.D, pack.layout_flags)
+            buf = self._prepared.get(key)
+            fresh = buf is None
+            if fresh:
+                device = self._keep[1][0].device
+                buf = torch.empty(_hip.PREPARED_OPERATOR_BYTES, dtype=torch.uint8, device=device)
+            flags = pack.layout_flags & ~1 if self.plan.family == FAMILY_FACEMASS else pack.layout_flags   # (not FM_J_FE)
+            try:
+                _hip.prepare_operator(self.plan.family, pack.D, pack.Np, pack.nf, pack.Nfp, flags, buf.data_ptr(),
+                                      stream_ptr)
+            except NotImplementedError:
+                continue
+            self._prepared[key] = buf
+            pack.prepared = buf.data_ptr()
+            done += 1
+        return done
 
     def _bind_planes(self, einsum: BatchedEinsum, arg_dict: Mapping[str, Any], outs: Sequence[Any]) -> bool:
         """Rows of 're,rij,ej->ei' that share u and D (e.g. the curl-type batch of
@@ -292,9 +334,15 @@ class _FamilyLaunch:
             if self.group_family == FAMILY_GRADPLANES:
                 _hip.check(lib.fe_gradplanes3d_f64(pack.j3, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                    pack.b, pack.layout_flags, pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_GRAD and pack.prepared:
+                _hip.check(lib.fe_grad3d_prepared_f64(pack.J, pack.D, pack.prepared, pack.v, pack.outs, pack.E,
+                                                      pack.Np, pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_GRAD:
                 _hip.check(lib.fe_grad_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.ndim, pack.Np,
                                            pack.b, pack.layout_flags, pack.variant, stream_ptr))
+            elif self.plan.family == FAMILY_DIV and pack.prepared:
+                _hip.check(lib.fe_div3d_prepared_f64(pack.J, pack.D, pack.prepared, pack.v, pack.outs, pack.E,
+                                                     pack.Np, pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIV:
                 _hip.check(lib.fe_div_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.ndim, pack.Np,
                                           pack.b, pack.layout_flags, pack.variant, stream_ptr))
@@ -305,9 +353,9 @@ class _FamilyLaunch:
                 _hip.check(lib.fe_divcomp3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
                                                 pack.layout_flags, pack.variant, stream_ptr))
             else:
-                _hip.check(lib.fe_facemass_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np,
-                                               pack.nf, pack.Nfp, pack.b, pack.layout_flags,
-                                               pack.variant, stream_ptr))
+                _hip.check(lib.fe_facemass_prepared_f64(pack.J, pack.D, pack.prepared, pack.v, pack.outs, pack.E,
+                                                        pack.Np, pack.nf, pack.Nfp, pack.b, pack.layout_flags,
+                                                        pack.variant, stream_ptr))
 
     def time_batch(self, n: int, stream_ptr: int) -> float:
         """Seconds for *n* launches of the whole batched einsum (HIP events)."""
@@ -378,7 +426,7 @@ class _GenericLaunch:
 
 
 def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
-          out_dict: Optional[Mapping[str, Any]], transform: Any):
+          out_dict: Optional[Mapping[str, Any]], transform: Any, prepare: bool = False):
     import torch
 
     q = _as_queue(cq)
@@ -402,6 +450,9 @@ def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
     variant = _variant_from_transform(transform)
     if plan is not None:
         bound = _FamilyLaunch(plan, einsum, arg_dict, outs, variant)
+        if _prepared_from_transform(transform, prepare):
+            with torch.cuda.device(q.torch_device):
+                bound.prepare_operators(q.stream_ptr)
     else:
         if variant not in (None, "auto", "generic", 0, 1):
             raise NotImplementedError(
@@ -504,7 +555,9 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
         validate_batched_einsum_transform(einsum, q, transform, schedule)
     arg_dict = generate_input_arrays(q, einsum, long_dim_length)
     out_dict = generate_out_arrays(q, einsum, long_dim_length)
-    _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform)
+    # one binding, many launches: the operator matrices are prepared once (see _FamilyLaunch.prepare_operators;
+    # `transform={"prepared": False}` times the launch that rebuilds its fragments from the plain arrays)
+    _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=True)
     with torch.cuda.device(q.torch_device):
         for _ in range(N_WARMUP_ROUNDS):
             bound.launch(q.stream_ptr)

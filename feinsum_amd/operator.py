@@ -45,10 +45,10 @@ class _GradDivLaunch:
     def __init__(self, grad: _FamilyLaunch, div: _FamilyLaunch) -> None:
         self._keep = (grad, div)
         g, d = grad.groups[0], div.groups[0]
-        self.args = (g.J, g.D, g.u, d.u, g.out, d.out, g.E, g.Np, grad.variant)
+        self.args = (g.J, g.D, g.prepared or d.prepared, g.u, d.u, g.out, d.out, g.E, g.Np, grad.variant)
 
     def launch(self, stream_ptr: int) -> None:
-        _hip.check(_hip.load_library().fe_graddiv3d_f64(*self.args, stream_ptr))
+        _hip.check(_hip.load_library().fe_graddiv3d_prepared_f64(*self.args, stream_ptr))
 
 
 class _WaveOpLaunch:
@@ -59,11 +59,11 @@ class _WaveOpLaunch:
     def __init__(self, grad: _FamilyLaunch, div: _FamilyLaunch, lift: _FamilyLaunch) -> None:
         self._keep = (grad, div, lift)
         g, d, m = grad.groups[0], div.groups[0], lift.groups[0]
-        self.args = (g.J, g.D, g.u, g.out, d.u, d.out, m.J, m.D, m.v, m.outs, g.E, g.Np, m.nf, m.Nfp,
-                     m.b, m.layout_flags, grad.variant)
+        self.args = (g.J, g.D, g.prepared or d.prepared, g.u, g.out, d.u, d.out, m.J, m.D, m.prepared, m.v, m.outs,
+                     g.E, g.Np, m.nf, m.Nfp, m.b, m.layout_flags, grad.variant)
 
     def launch(self, stream_ptr: int) -> None:
-        _hip.check(_hip.load_library().fe_waveop3d_f64(*self.args, stream_ptr))
+        _hip.check(_hip.load_library().fe_waveop3d_prepared_f64(*self.args, stream_ptr))
 
 
 def _single_plain_group(b: Any, family: int) -> bool:
@@ -158,6 +158,13 @@ class BoundOperator:
         for b in self.launches:
             b.launch(s)
 
+    def refresh_operators(self) -> None:
+        """Re-prepare the operator matrices after their arrays were changed in place (the prepared copies
+        are snapshots taken at bind time; the fused launches hold the same buffers)."""
+        for b in getattr(self, "_stages", []):
+            if isinstance(b, _FamilyLaunch) and b._prepared:
+                b.prepare_operators(self.queue.stream_ptr)
+
     def capture(self) -> "BoundOperator":
         """Record one evaluation of the operator in a HIP graph (the launchers neither allocate nor
         synchronise, so they can be captured); :meth:`replay` then enqueues it with a single call.
@@ -204,17 +211,23 @@ class BoundOperator:
 
 def bind_operator(stages: Sequence[StageT], cq: Any, *,
                   out_dicts: Optional[Sequence[Optional[Mapping[str, Any]]]] = None,
-                  transform: Any = None, fuse: bool = True) -> BoundOperator:
-    """Bind every stage (shape / dtype / device checks as in ``evaluate``) and merge what can share a launch."""
+                  transform: Any = None, fuse: bool = True, prepare: bool = True) -> BoundOperator:
+    """Bind every stage (shape / dtype / device checks as in ``evaluate``) and merge what can share a launch.
+
+    *prepare*: write the operator matrices once in the kernels' fragment layout (``fe_prepare_operator``),
+    so that the launches of this bound operator skip rebuilding them.  The prepared copies are
+    snapshots: after changing an operator array in place call :meth:`BoundOperator.refresh_operators`."""
     if out_dicts is not None and len(out_dicts) != len(stages):
         raise ValueError("out_dicts: need one entry (or None) per stage")
     queue, bound, outputs = None, [], []
     for k, (expr, arrays) in enumerate(stages):
-        q, b, outs = _bind(expr, cq, arrays, None if out_dicts is None else out_dicts[k], transform)
+        q, b, outs = _bind(expr, cq, arrays, None if out_dicts is None else out_dicts[k], transform, prepare=prepare)
         queue = queue or q
         bound.append(b)
         outputs.append(MappingProxyType(dict(zip(expr.output_names, outs))))
-    return BoundOperator(queue, _merge(bound) if fuse else bound, outputs)
+    op = BoundOperator(queue, _merge(bound) if fuse else bound, outputs)
+    op._stages = bound
+    return op
 
 
 def evaluate_operator(stages: Sequence[StageT], cq: Any, *,
@@ -223,7 +236,7 @@ def evaluate_operator(stages: Sequence[StageT], cq: Any, *,
     """Enqueue all stages; returns one ``{"_fe_out": tensor, ...}`` mapping per stage."""
     import torch
 
-    op = bind_operator(stages, cq, out_dicts=out_dicts, transform=transform, fuse=fuse)
+    op = bind_operator(stages, cq, out_dicts=out_dicts, transform=transform, fuse=fuse, prepare=False)
     if op.queue is not None:
         with torch.cuda.device(op.queue.torch_device):
             op.launch()

@@ -26,7 +26,7 @@
  *     available from fe_last_error() (thread-local).
  *   - thread-safety: re-entrant; distinct streams may be driven from distinct
  *     host threads.  No global mutable state besides an init-once attribute
- *     cache.
+ *     cache and the record of prepared-operator buffers (fe_prepare_operator).
  *
  * `variant` selects the kernel implementation (the build's replacement for the
  * reference's transform archive lookup, sql_utils.py:247-294):
@@ -214,6 +214,62 @@ int fe_facemass_f64(const double* J, const double* R,
                     int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
                     int32_t layout_flags, int32_t variant, void* stream);
 
+/* ---- prepared operators ------------------------------------------------------------------
+ * The operator matrices (D of grad / div, R or L of face-mass) are constant across the launches
+ * of a time-stepping code, while rebuilding their MFMA register fragments from the plain array is
+ * most of a launch's fixed cost (5-9 us of prologue: half of a launch at the reference's default
+ * E = 1e5, src/feinsum/measure.py:202).  fe_prepare_operator writes an operator ONCE in the
+ * kernels' fragment layout; the *_prepared_* launchers then fetch the fragments with coalesced
+ * loads instead (no LDS staging, no block barrier).  It plays the role of the operator prefetch
+ * of the reference's transforms (tuning/impls/xre_rij_ej_to_xei.py:26-275, `prftch_u_to_local`
+ * and the D slab in __local) -- hoisted out of the launch altogether.
+ *
+ *   family    FE_FAMILY_GRAD, FE_FAMILY_DIV or FE_FAMILY_GRADDIV: `op` = D[3][Np][Np]
+ *             (FE_OP_TRANSPOSED in `flags` for [3][Np(j)][Np(i)]); one buffer serves grad AND div.
+ *             FE_FAMILY_FACEMASS: `op` = R / L with FE_FM_R_IFJ / FE_FM_R_T in `flags`.
+ *   prepared  caller-owned DEVICE buffer of FE_PREPARED_OPERATOR_BYTES bytes, 16-byte aligned;
+ *             written asynchronously on `stream`.
+ * Tetrahedra p = 1..4 (FE_EUNSUPPORTED otherwise: launch without a prepared operator).
+ *
+ * INVALIDATION IS THE CALLER'S: the buffer is a snapshot of `op`.  After changing the operator's
+ * values call fe_prepare_operator again (same buffer is fine) before the next prepared launch;
+ * the launchers cannot see that the snapshot is stale.  They do refuse (FE_EINVAL) a buffer that
+ * this process did not prepare, or prepared for another shape / layout flag -- a host-side record
+ * keyed by the buffer address, the library's only mutable state besides the init-once kernel
+ * attribute cache (mutex protected; prepare a buffer before handing it to other threads).
+ * A prepared launcher given NULL, or running a kernel without a prepared form (tiled / generic
+ * variants, multi-plane grad batches), behaves exactly like its plain counterpart; results are
+ * bitwise identical either way. */
+#define FE_PREPARED_OPERATOR_BYTES (96 * 1024)
+int fe_prepare_operator(int32_t family, const double* op, int32_t Np, int32_t nf, int32_t Nfp,
+                        int32_t flags, void* prepared, void* stream);
+
+/* fe_grad3d_batched_f64 / fe_div3d_batched_f64 / fe_facemass_f64 / fe_graddiv3d_f64 /
+ * fe_waveop3d_f64 with the operator(s) ALSO given in prepared form (or NULL). */
+int fe_grad3d_prepared_f64(const double* J, const double* D, const void* D_prepared,
+                           const double* const* u, double* const* out,
+                           int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                           int32_t variant, void* stream);
+int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepared,
+                          const double* const* u, double* const* out,
+                          int64_t E, int32_t Np, int32_t b, int32_t op_flags,
+                          int32_t variant, void* stream);
+int fe_facemass_prepared_f64(const double* J, const double* R, const void* R_prepared,
+                             const double* const* v, double* const* out,
+                             int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                             int32_t layout_flags, int32_t variant, void* stream);
+int fe_graddiv3d_prepared_f64(const double* J, const double* D, const void* D_prepared,
+                              const double* u_grad, const double* v_div,
+                              double* grad_out, double* div_out,
+                              int64_t E, int32_t Np, int32_t variant, void* stream);
+int fe_waveop3d_prepared_f64(const double* J, const double* D, const void* D_prepared,
+                             const double* u_grad, double* grad_out,
+                             const double* v_div, double* div_out,
+                             const double* Jface, const double* R, const void* R_prepared,
+                             const double* const* f, double* const* lift,
+                             int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
+                             int32_t fm_layout_flags, int32_t variant, void* stream);
+
 /* Text table of the MFMA / tiled kernels configured so far in this process, one line each:
  * threads, VGPRs, scratch, LDS per block and the resident blocks per CU the HIP occupancy query
  * reports next to the number the launch geometry assumes.  (A kernel is configured -- and the
@@ -245,6 +301,7 @@ typedef struct fe_argpack {
     int32_t Np, nf, Nfp, b, layout_flags, variant;   /* layout_flags: FE_FM_* or FE_OP_* by family */
     const double* const* j3;  /* FE_FAMILY_GRADPLANES: 3 ptrs; v = u (b), outs = planes (3 b) */
     int32_t ndim;             /* grad / div: 0 or 3 = tetrahedra, 2 = triangles (v / outs, any b) */
+    const void* prepared;     /* the operator D (or R) in prepared form, or NULL (fe_prepare_operator) */
 } fe_argpack;
 
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed

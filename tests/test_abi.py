@@ -71,6 +71,24 @@ def test_argument_validation_without_gpu():
     assert _hip.load_library().fe_last_error() is not None
 
 
+def test_prepared_operator_argument_checks_without_gpu():
+    with pytest.raises(InvalidParameterError, match="null"):
+        _hip.prepare_operator(1, 0, 35, 0, 0, 0, 0)
+    with pytest.raises(InvalidParameterError, match="aligned"):
+        _hip.prepare_operator(1, 8, 35, 0, 0, 0, 24)
+    with pytest.raises(NotImplementedError, match="p = 1..4"):
+        _hip.prepare_operator(1, 8, 56, 0, 0, 0, 64)
+    with pytest.raises(NotImplementedError, match="no prepared form"):
+        _hip.prepare_operator(5, 8, 35, 0, 0, 0, 64)
+    with pytest.raises(InvalidParameterError, match="flags"):
+        _hip.prepare_operator(4, 8, 35, 4, 15, 1, 64)          # FE_FM_J_FE is not an operator flag
+    # a buffer this process never prepared is refused before anything is launched
+    lib = _hip.load_library()
+    ptrs = _hip._ptr_array([8])
+    rc = lib.fe_grad3d_prepared_f64(8, 8, 4096, ptrs, ptrs, 10, 35, 1, 0, 0, 0)
+    assert rc == _hip.FE_EINVAL and b"fe_prepare_operator" in lib.fe_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("FEINSUM_HIP_LIB", str(tmp_path / "nope.so"))
     monkeypatch.setattr(_hip, "_lib", None)

@@ -19,7 +19,7 @@ def stage(family, reads, writes, b=1):
     s.plan = KernelPlan(family, 0, {}, "e", {"Np": 35})
     s.variant = 0
     g = SimpleNamespace(J=J[0], D=D[0], E=1000, Np=35, b=b, ndim=3, u=reads[-1][0], out=writes[0][0],
-                        nf=4, Nfp=15, layout_flags=0, v=None, outs=None)
+                        nf=4, Nfp=15, layout_flags=0, v=None, outs=None, prepared=None)
     s.groups = [g]
     s.group_family = family
     s.reads, s.writes = tuple(reads), tuple(writes)

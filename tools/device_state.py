@@ -51,11 +51,27 @@ def _current_level(text):
     return None
 
 
-def sample(ordinal: int = 0) -> dict:
+def find_card(ordinal: int = 0, pci: tuple | None = None):
+    """sysfs device directory of a GPU: by PCI (domain, bus, device) when given -- HIP ordinals and
+    DRM card numbers need not agree -- else the ordinal-th card that has clock tables."""
     cards = _cards()
     if not cards:
+        return None
+    if pci is not None:
+        want = "%04x:%02x:%02x." % tuple(int(x) for x in pci)
+        for dev in cards:
+            try:
+                if dev.resolve().name.startswith(want):
+                    return dev
+            except OSError:
+                pass
+    return cards[min(ordinal, len(cards) - 1)]
+
+
+def sample(ordinal: int = 0, pci: tuple | None = None) -> dict:
+    dev = find_card(ordinal, pci)
+    if dev is None:
         return {"error": "no amdgpu card with pp_dpm_sclk under /sys/class/drm"}
-    dev = cards[min(ordinal, len(cards) - 1)]
     out: dict = {"t": round(time.time(), 3), "card": dev.parent.name}
     for dom in ("sclk", "mclk", "fclk", "socclk"):
         lvl = _current_level(_read(dev / f"pp_dpm_{dom}"))
@@ -80,6 +96,45 @@ def sample(ordinal: int = 0) -> dict:
             if v and v.isdigit():
                 out[f"freq_{label or f.name[:-6]}_mhz"] = round(int(v) * 1e-6)
     return out
+
+
+class Sampler:
+    """Background sampling while a measurement runs (an instantaneous reading taken before or after it
+    sees an idle device: the clocks fall back within milliseconds).  `with Sampler(0) as sm: ...;
+    sm.summary()` -> mean / min / max of every numeric reading."""
+
+    def __init__(self, ordinal: int = 0, pci: tuple | None = None, period_s: float = 0.02) -> None:
+        import threading
+
+        self.ordinal, self.pci, self.period = ordinal, pci, period_s
+        self.rows: list = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self) -> None:
+        while not self._stop.is_set():
+            self.rows.append(sample(self.ordinal, self.pci))
+            self._stop.wait(self.period)
+
+    def __enter__(self) -> "Sampler":
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+
+    def summary(self) -> dict:
+        out: dict = {"samples": len(self.rows)}
+        if not self.rows:
+            return out
+        out["card"] = self.rows[0].get("card")
+        keys = sorted({k for r in self.rows for k, v in r.items() if isinstance(v, (int, float)) and k != "t"})
+        for k in keys:
+            vals = [r[k] for r in self.rows if isinstance(r.get(k), (int, float))]
+            if vals:
+                out[k] = {"mean": round(sum(vals) / len(vals), 1), "min": min(vals), "max": max(vals)}
+        return out
 
 
 if __name__ == "__main__":

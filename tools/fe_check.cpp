@@ -2,7 +2,7 @@
 // host loop nest and device timing, without Python.  Used for quick GPU
 // iterations and as the program under rocprofv3 (fast start-up).
 //
-//   fe_check <family:grad|div|facemass|graddiv> <E> [variant=0] [launches=20] [check=1]
+//   fe_check <family:grad|div|facemass|graddiv> <E> [variant=0] [launches=20] [check=1]      (FE_PREPARED=1: prepared operators)
 //
 // Build: hipcc -O2 tools/fe_check.cpp -Lfeinsum_amd -lfeinsum_hip -Wl,-rpath,'$ORIGIN/../feinsum_amd' -o build/fe_check
 #include <hip/hip_runtime.h>
@@ -81,20 +81,29 @@ static int ab_main(int argc, char** argv) {
         a.v = dv.data(); a.outs = dout.data();
         family = FE_FAMILY_FACEMASS; flops = 17040.0 * E; bytes = 3072.0 * E;
     }
+    // variant codes >= 100000: the same variant (code - 100000) with the operator in prepared form
+    void* prepared = nullptr;
+    CK(hipMalloc(&prepared, FE_PREPARED_OPERATOR_BYTES));
+    FE(fe_prepare_operator(family, a.D, Np, family == FE_FAMILY_FACEMASS ? nf : 0, family == FE_FAMILY_FACEMASS ? Nfp : 0, 0,
+                           prepared, nullptr));
+    auto set_variant = [&](int code) {
+        a.prepared = code >= 100000 ? prepared : nullptr;
+        a.variant = code >= 100000 ? code - 100000 : code;
+    };
     std::vector<std::vector<float>> t(variants.size());
     float ms;
-    for (size_t v = 0; v < variants.size(); ++v) { a.variant = variants[v]; FE(fe_time_launches(family, &a, 3, nullptr, &ms)); }
+    for (size_t v = 0; v < variants.size(); ++v) { set_variant(variants[v]); FE(fe_time_launches(family, &a, 3, nullptr, &ms)); }
     for (int r = 0; r < rounds; ++r)
         for (size_t v = 0; v < variants.size(); ++v) {
-            a.variant = variants[v];
+            set_variant(variants[v]);
             FE(fe_time_launches(family, &a, launches, nullptr, &ms));
             t[v].push_back(ms / launches);
         }
     typedef int (*clk_fn)(unsigned long long*);
     clk_fn rd = (clk_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_clock");
     for (size_t v = 0; v < variants.size() && rd; ++v)
-        if (variants[v] >= 1000 && ((variants[v] - 1000) & 32)) {
-            a.variant = variants[v];
+        if (variants[v] % 100000 >= 1000 && ((variants[v] % 100000 - 1000) & 32)) {
+            set_variant(variants[v]);
             FE(fe_time_launches(family, &a, launches, nullptr, &ms));
             unsigned long long c[2];
             rd(c);
@@ -135,7 +144,7 @@ static int ab_main(int argc, char** argv) {
     for (size_t v = 0; v < variants.size(); ++v) {
         std::sort(t[v].begin(), t[v].end());
         const float med = t[v][t[v].size() / 2], mn = t[v].front();
-        printf("%s E=%lld variant %5d: median %.4f ms (%.0f GFLOP/s, %.0f GB/s)  min %.4f ms  max %.4f ms\n", fam.c_str(),
+        printf("%s E=%lld variant %6d: median %.4f ms (%.0f GFLOP/s, %.0f GB/s)  min %.4f ms  max %.4f ms\n", fam.c_str(),
                (long long)E, variants[v], med, flops / med * 1e-6, bytes / med * 1e-6, mn, t[v].back());
     }
     return 0;
@@ -233,6 +242,12 @@ int main(int argc, char** argv) {
         fe_argpack a;
         memset(&a, 0, sizeof a);
         a.J = J; a.D = D; a.E = E; a.Np = Np; a.variant = variant;
+        if (getenv("FE_PREPARED") && atoi(getenv("FE_PREPARED"))) {
+            void* prepared = nullptr;
+            CK(hipMalloc(&prepared, FE_PREPARED_OPERATOR_BYTES));
+            FE(fe_prepare_operator(FE_FAMILY_GRADDIV, D, Np, 0, 0, 0, prepared, nullptr));
+            a.prepared = prepared;
+        }
         int family;
         if (fam == "grad") { family = FE_FAMILY_GRAD; a.u = u; a.out = og; }
         else if (fam == "div") { family = FE_FAMILY_DIV; a.u = v; a.out = od; }
@@ -295,6 +310,12 @@ int main(int argc, char** argv) {
         memset(&a, 0, sizeof a);
         a.J = J; a.D = R; a.v = dv.data(); a.outs = dout.data();
         a.E = E; a.Np = Np; a.nf = nf; a.Nfp = Nfp; a.b = b; a.variant = variant;
+        if (getenv("FE_PREPARED") && atoi(getenv("FE_PREPARED"))) {
+            void* prepared = nullptr;
+            CK(hipMalloc(&prepared, FE_PREPARED_OPERATOR_BYTES));
+            FE(fe_prepare_operator(FE_FAMILY_FACEMASS, R, Np, nf, Nfp, 0, prepared, nullptr));
+            a.prepared = prepared;
+        }
         flops = (double)fe_flops_per_element(FE_FAMILY_FACEMASS, Np, nf, Nfp, b) * E;
         bytes = 8.0 * (nf + b * nf * Nfp + b * Np) * E + 8.0 * nf * Np * Nfp;
         float w;
