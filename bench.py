@@ -385,8 +385,12 @@ def main() -> None:
     ap.add_argument("--no-protocol", action="store_true", help="skip the reference-protocol timing (2 s)")
     ap.add_argument("--setup-launches", type=int, default=SETUP_LAUNCHES,
                     help="untimed launches before the warm-up steps (reported in the line)")
-    ap.add_argument("--no-prepare", action="store_true",
-                    help="rebuild the operator fragments in every launch instead of preparing them once at bind time")
+    ap.add_argument("--prepare", action="store_true",
+                    help="prepare the operator matrices once at bind time (fe_prepare_operator) instead of rebuilding the "
+                         "MFMA fragments in every launch; measured: no gain, see DESIGN.md")
+    ap.add_argument("--placement", default="tuned", choices=["tuned", "separate"],
+                    help="tuned: all arrays in one arena with the spacing that times fastest (feinsum_amd/placement.py); "
+                         "separate: one torch allocation per array")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
     args = ap.parse_args()
@@ -408,24 +412,72 @@ def main() -> None:
     sync = lambda: torch.cuda.synchronize(device)   # noqa: E731
 
     exprs = _einsums()[args.workload]
-    stages, out_dicts, outs_all, flops_step, bytes_step, shared = [], [], [], 0.0, 0.0, {}
-    for k, expr in enumerate(exprs):
-        dev = _device_inputs(expr, E, device, seed=1000 * info.rank + k)
-        for name in ("J", "R"):          # div and grad of one operator share J and D
-            if name in dev:
-                dev[name] = shared.setdefault(name, dev[name])
-        outs = measure.generate_out_arrays(q, expr, E)
-        stages.append((expr, dev))
-        out_dicts.append(outs)
-        outs_all += list(outs.values())
-        flops_step += f.count_ops(expr, long_dim_length=E)
-        bytes_step += measure._get_footprint_gbytes(expr, E) * 1e9
+    flops_step = sum(float(f.count_ops(expr, long_dim_length=E)) for expr in exprs)
+    bytes_step = sum(measure._get_footprint_gbytes(expr, E) * 1e9 for expr in exprs)
     if len(exprs) > 1:                   # J and D counted once
         bytes_step -= 8.0 * (9 * E + 3 * NP * NP)
-    # The operator matrices are constant across the steps of a time integrator: they are written once, here, in
-    # the kernels' MFMA fragment layout (fe_prepare_operator) and every launch fetches them from there.
-    op = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
-                                prepare=not args.no_prepare)
+
+    def bind(stages, out_dicts):
+        return operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
+                                      prepare=args.prepare)
+
+    def separate_allocations():
+        """One torch allocation per array (what round 1 measured)."""
+        stages, out_dicts, shared = [], [], {}
+        for k, expr in enumerate(exprs):
+            dev = _device_inputs(expr, E, device, seed=1000 * info.rank + k)
+            for name in ("J", "R"):          # div and grad of one operator share J and D
+                if name in dev:
+                    dev[name] = shared.setdefault(name, dev[name])
+            stages.append((expr, dev))
+            out_dicts.append(measure.generate_out_arrays(q, expr, E))
+        return stages, out_dicts
+
+    def step_batch_of(op_):
+        s_ = q.stream_ptr
+        if len(op_.launches) == 1 and hasattr(op_.launches[0], "time_batch"):
+            return lambda n: op_.launches[0].time_batch(n, s_)    # HIP events on the launch stream (fe_time_launches)
+        return lambda n: op_.time_batch(n, s_)                    # same, through torch's event objects
+
+    placement_report = {"mode": "separate", "what": "one torch allocation per array"}
+    if args.placement == "tuned":
+        from feinsum_amd import placement
+
+        # every array of the workload, in layout order: per stage the inputs (sorted names; J and D of the grad / div
+        # pair once), then the outputs
+        arrays, seen = [], set()
+        for k, expr in enumerate(exprs):
+            for name in sorted(expr.all_args):
+                key = name if name in ("J", "R") else f"{k}:{name}"
+                if key not in seen:
+                    seen.add(key)
+                    shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[name])
+                    arrays.append((key, shape, torch.float64))
+            out_shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+            arrays += [(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names]
+
+        def fill(key, view):
+            if ">" in key:
+                view.zero_()
+            else:
+                g = torch.Generator(device=device).manual_seed(1000 * info.rank + sum(map(ord, key)))
+                view.uniform_(0.0, 1.0, generator=g)
+
+        def stages_of(views):
+            stages, out_dicts = [], []
+            for k, expr in enumerate(exprs):
+                stages.append((expr, {name: views[name if name in ("J", "R") else f"{k}:{name}"]
+                                      for name in expr.all_args}))
+                out_dicts.append({name: views[f"{k}>{name}"] for name in expr.output_names})
+            return stages, out_dicts
+
+        arena, views, placement_report = placement.tune_gap(
+            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill)
+        stages, out_dicts = stages_of(views)
+    else:
+        stages, out_dicts = separate_allocations()
+    outs_all = [t for od in out_dicts for t in od.values()]
+    op = bind(stages, out_dicts)
     prepared = any(getattr(b, "_prepared", None) for b in op._stages)
 
     s = q.stream_ptr
@@ -438,10 +490,7 @@ def main() -> None:
     for _ in range(args.warmup):
         op.launch(s)
 
-    def step_batch(n):
-        if len(op.launches) == 1 and hasattr(op.launches[0], "time_batch"):
-            return op.launches[0].time_batch(n, s)    # HIP events on the launch stream (fe_time_launches)
-        return op.time_batch(n, s)                    # same, through torch's event objects
+    step_batch = step_batch_of(op)
 
     wall_s, kernel_s = timed_region(step_batch, args.steps, sync, device)
 
@@ -464,21 +513,14 @@ def main() -> None:
         device_under_load = sampler.summary()
         protocol_ms = {"device": dev_s / n_launch * 1e3, "host": host_s / n_launch * 1e3, "launches": n_launch}
 
-    # the same launch with the fragments rebuilt from the plain operator arrays in every launch (A/B, untimed region)
-    unprepared_ms = None
-    if prepared and not args.no_protocol:
-        op_plain = operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
-                                          prepare=False)
-        for _ in range(args.warmup):
-            op_plain.launch(s)
-        sync()
-        if len(op_plain.launches) == 1 and hasattr(op_plain.launches[0], "time_batch"):
-            unprepared_ms = op_plain.launches[0].time_batch(args.steps, s) / args.steps * 1e3
-        else:
-            unprepared_ms = op_plain.time_batch(args.steps, s) / args.steps * 1e3
-        for _ in range(3):
-            op.launch(s)        # the outputs reduced below are those of the prepared launch
-        sync()
+    # A/B outside the timed region: the same launch on one-torch-allocation-per-array operands
+    separate_ms = None
+    if args.placement == "tuned" and not args.no_protocol:
+        op_sep = bind(*separate_allocations())
+        sb = step_batch_of(op_sep)
+        sb(max(args.warmup, 10))
+        separate_ms = sb(args.steps) / args.steps * 1e3
+        del op_sep, sb
 
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
@@ -496,8 +538,8 @@ def main() -> None:
     if info.rank == 0:
         extra = {"result_reduction_ms": round(reduction_ms, 3), "result_allgather_ms": round(allgather_ms, 3),
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
-                 "operator_prepared": prepared,
-                 "kernel_ms_unprepared": None if unprepared_ms is None else round(unprepared_ms, 5),
+                 "operator_prepared": prepared, "placement": placement_report,
+                 "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
                  "dist_backend": info.backend if info.world_size > 1 else None}
         if protocol_ms is not None:
             extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)

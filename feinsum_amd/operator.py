@@ -211,11 +211,13 @@ class BoundOperator:
 
 def bind_operator(stages: Sequence[StageT], cq: Any, *,
                   out_dicts: Optional[Sequence[Optional[Mapping[str, Any]]]] = None,
-                  transform: Any = None, fuse: bool = True, prepare: bool = True) -> BoundOperator:
+                  transform: Any = None, fuse: bool = True, prepare: bool = False) -> BoundOperator:
     """Bind every stage (shape / dtype / device checks as in ``evaluate``) and merge what can share a launch.
 
-    *prepare*: write the operator matrices once in the kernels' fragment layout (``fe_prepare_operator``),
-    so that the launches of this bound operator skip rebuilding them.  The prepared copies are
+    *prepare* (off by default: the bound arrays stay the operands, whatever is written into them between
+    launches): write the operator matrices once in the kernels' fragment layout
+    (``fe_prepare_operator``), so that the launches of this bound operator skip rebuilding them -- for
+    operators that stay constant across launches, as in a time integrator.  The prepared copies are
     snapshots: after changing an operator array in place call :meth:`BoundOperator.refresh_operators`."""
     if out_dicts is not None and len(out_dicts) != len(stages):
         raise ValueError("out_dicts: need one entry (or None) per stage")
@@ -236,7 +238,7 @@ def evaluate_operator(stages: Sequence[StageT], cq: Any, *,
     """Enqueue all stages; returns one ``{"_fe_out": tensor, ...}`` mapping per stage."""
     import torch
 
-    op = bind_operator(stages, cq, out_dicts=out_dicts, transform=transform, fuse=fuse, prepare=False)
+    op = bind_operator(stages, cq, out_dicts=out_dicts, transform=transform, fuse=fuse)
     if op.queue is not None:
         with torch.cuda.device(op.queue.torch_device):
             op.launch()

@@ -1,0 +1,53 @@
+"""feinsum_amd.placement: arena layout arithmetic (CPU) and the tuned layout on the device."""
+
+import pytest
+
+from feinsum_amd import placement
+
+MIB = placement.MIB
+
+
+def test_layout_offsets():
+    sizes = [3 * MIB + 5, 10, 7 * MIB]
+    assert placement.layout_offsets(sizes, 0) == [0, 4 * MIB, 6 * MIB]
+    offs = placement.layout_offsets(sizes, 100 * MIB)
+    assert offs == [0, 104 * MIB, 206 * MIB]
+    assert all(o % placement.ALIGN == 0 for o in offs)
+    # arrays never overlap and the arena holds the widest layout
+    for gap in (0, MIB, 136 * MIB):
+        offs = placement.layout_offsets(sizes, gap)
+        assert all(a + s <= b for a, s, b in zip(offs, sizes, offs[1:]))
+        assert offs[-1] + sizes[-1] <= placement.arena_bytes(sizes, 136 * MIB)
+
+
+@pytest.mark.gpu
+def test_tuned_layout_gives_the_same_results():
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd import measure
+
+    E, expr = 4099, dg.grad()
+    q = f.DeviceQueue(0)
+    arrays = [(n, tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[n]), torch.float64)
+              for n in sorted(expr.all_args)] + [("_fe_out", (3, E, 35), torch.float64)]
+
+    def fill(name, view):
+        if name == "_fe_out":
+            view.fill_(float("nan"))
+        else:
+            view.uniform_(0.0, 1.0, generator=torch.Generator(device="cuda").manual_seed(len(name)))
+
+    def make_step(views):
+        _, bound, _ = measure._bind(expr, q, {n: views[n] for n in expr.all_args}, {"_fe_out": views["_fe_out"]}, None)
+        return lambda n: bound.time_batch(n, q.stream_ptr)
+
+    arena, views, report = placement.tune_gap(arrays, "cuda", make_step, gaps_mib=(0, 8, 40), fill=fill,
+                                              rounds=1, launches=2, warmup=1)
+    assert report["best_gap_mib"] in (0, 8, 40) and set(report["ms_by_gap_mib"]) == {"0", "8", "40"}
+    assert all(v.data_ptr() % placement.ALIGN == arena.buf.data_ptr() % placement.ALIGN for v in views.values())
+    make_step(views)(1)
+    q.finish()
+    ref = f.evaluate(expr, 0, {n: views[n].clone() for n in expr.all_args}, wait=True)["_fe_out"]
+    assert torch.equal(views["_fe_out"], ref)
