@@ -389,8 +389,9 @@ def main() -> None:
                     help="prepare the operator matrices once at bind time (fe_prepare_operator) instead of rebuilding the "
                          "MFMA fragments in every launch; measured: no gain, see DESIGN.md")
     ap.add_argument("--placement", default="tuned", choices=["tuned", "separate"],
-                    help="tuned: all arrays in one arena with the spacing that times fastest (feinsum_amd/placement.py); "
-                         "separate: one torch allocation per array")
+                    help="tuned: all arrays in one large arena, at the position that times fastest "
+                         "(feinsum_amd/placement.py); separate: one torch allocation per array")
+    ap.add_argument("--arena-gib", type=float, default=66.0, help="size of the placement arena (tuned placement)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
     args = ap.parse_args()
@@ -471,8 +472,9 @@ def main() -> None:
                 out_dicts.append({name: views[f"{k}>{name}"] for name in expr.output_names})
             return stages, out_dicts
 
-        arena, views, placement_report = placement.tune_gap(
-            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill)
+        arena, views, placement_report = placement.tune_base(
+            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill,
+            arena_gib=args.arena_gib / max(1, info.world_size if os.environ.get("FEINSUM_DIST_BACKEND") == "gloo" else 1))
         stages, out_dicts = stages_of(views)
     else:
         stages, out_dicts = separate_allocations()

@@ -8,6 +8,7 @@ mode "gap":   every array starts `gap` bytes behind the (2 MiB-rounded) end of t
               gap = 0, 0.25, 0.5, ... MiB (fine) then 2 MiB steps (coarse)
 mode "out":   inputs packed, only the outputs are shifted by the gap
 mode "base":  everything packed, the whole layout shifted inside the arena by the gap
+mode "region": arrays 64 MiB apart, the whole layout moved through a 48 GiB arena in 1 GiB steps
 One line per point: gap, median ms, min ms.
 """
 
@@ -38,15 +39,20 @@ def main() -> None:
     nbytes = lambda s: 8 * int(torch.Size(s).numel())   # noqa: E731
     n_arrays = len(names) + len(expr.output_names)
     wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
+    import os
     max_gap = (1300 if wide else 72) * MIB
+    if os.environ.get("FE_GAPS"):
+        max_gap = max(int(x) for x in os.environ["FE_GAPS"].split(",")) * MIB
+    if mode == "region":
+        max_gap = 64 * MIB
     total = sum(nbytes(s) for s in shape_of.values()) + len(expr.output_names) * nbytes(out_shape) \
-        + n_arrays * (max_gap + 4 * MIB) + 8 * MIB
+        + n_arrays * (max_gap + 4 * MIB) + 8 * MIB + ((int(os.environ.get("FE_REGION_GIB", "48")) + 1) * 1024 * MIB if mode == "region" else 0)
     arena = torch.empty(total, dtype=torch.uint8, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(0)
     src = {n: torch.rand(s, dtype=torch.float64, device="cuda", generator=g) for n, s in shape_of.items()}
 
     def layout(gap):
-        off, dev, outs = (gap if mode == "base" else 0), {}, {}
+        off, dev, outs = (gap if mode in ("base", "region") else 0), {}, {}
 
         def carve(nb, shape, extra):
             nonlocal off
@@ -56,10 +62,12 @@ def main() -> None:
             return t
 
         for k, n in enumerate(names):
-            dev[n] = carve(nbytes(shape_of[n]), shape_of[n], gap if (mode == "gap" and k > 0) else 0)
+            dev[n] = carve(nbytes(shape_of[n]), shape_of[n],
+                           gap if (mode == "gap" and k > 0) else (64 * MIB if (mode == "region" and k > 0) else 0))
             dev[n].copy_(src[n])
         for on in expr.output_names:
-            outs[on] = carve(nbytes(out_shape), out_shape, gap if mode in ("gap", "out") else 0)
+            outs[on] = carve(nbytes(out_shape), out_shape,
+                             gap if mode in ("gap", "out") else (64 * MIB if mode == "region" else 0))
         return dev, outs
 
     def time_it(dev, outs):
@@ -73,6 +81,11 @@ def main() -> None:
     gaps = [int(x * MIB / 4) for x in range(0, 17)] + [x * MIB for x in range(6, 72, 2)]
     if wide:
         gaps = [x * MIB for x in range(0, 1300, 8)]
+    if mode == "region":
+        gaps = [x * 1024 * MIB for x in range(0, int(os.environ.get("FE_REGION_GIB", "48")) + 1, int(os.environ.get("FE_REGION_STEP", "1")))] * 2
+    import os
+    if os.environ.get("FE_GAPS"):          # explicit list, MiB
+        gaps = [int(x) * MIB for x in os.environ["FE_GAPS"].split(",")]
     for gap in gaps:
         dev, outs = layout(gap)
         med, mn = time_it(dev, outs)
