@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
-    "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64",
+    "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64",
 )
 
 _c_double_p = C.c_void_p   # device pointers travel as plain integers
@@ -138,6 +138,9 @@ def load_library() -> C.CDLL:
     lib.fe_facemass_f64.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_divcomp_f64.restype = C.c_int
+    lib.fe_divcomp_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.fe_prepare_operator.restype = C.c_int
     lib.fe_prepare_operator.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]

@@ -185,6 +185,49 @@ __device__ __forceinline__ void store_prepared_fragment(void* section, int f, in
     reinterpret_cast<double*>(section)[((f >> 1) * 64 + lane) * 2 + (f & 1)] = v;
 }
 
+// ---- [rows][NP] tiles in LDS when NP is a multiple of 8 (p = 5: NP = 56) ---------------------------
+// A row is NP * 8 = 448 bytes = 192 mod 256: rows four apart start on the same banks, so the
+// column-wise accesses of the MFMA layouts (the 16 rows n of one column: B-fragment reads of the u
+// tile, accumulator writes into the output transposition buffer) conflict four ways -- at p = 5
+// 57 % of all LDS cycles were bank conflicts (profiles/r02/p5_pmc_before.txt).  Row n is therefore
+// ROTATED by rot(n) = (n / 4) mod 4 sixteen-byte chunks: column accesses of the 32 lanes of a
+// ds_read_b64 group then fall on 32 different bank pairs (24 b + 2 a + g, n = 4 a + b), rows stay
+// contiguous modulo the wrap, and a row-major copy needs no padding: the LDS-DMA that brings a tile in
+// simply fetches, for LDS chunk q, the global chunk tile_src_chunk(q).
+template <int NP>
+__device__ __forceinline__ constexpr bool tile_rotated() { return NP % 8 == 0 && NP >= 32; }
+template <int NP>
+__device__ __forceinline__ int tile_rot(int row) { return tile_rotated<NP>() ? ((row >> 2) & 3) : 0; }
+template <int NP>
+__device__ __forceinline__ int tile_index(int row, int col) {   // position (doubles) of element (row, col)
+    if constexpr (tile_rotated<NP>()) {
+        const int c = col + 2 * tile_rot<NP>(row);
+        return row * NP + (c >= NP ? c - NP : c);
+    } else {
+        return row * NP + col;
+    }
+}
+template <int NP>
+__device__ __forceinline__ int tile_src_chunk(int q) {   // LDS chunk q holds this chunk of the row-major tile
+    if constexpr (tile_rotated<NP>()) {
+        constexpr int CPR = NP / 2;
+        const int row = q / CPR, p = q - row * CPR, s = p - tile_rot<NP>(row);
+        return row * CPR + (s < 0 ? s + CPR : s);
+    } else {
+        return q;
+    }
+}
+template <int NP>
+__device__ __forceinline__ int tile_dst_chunk(int q) {   // chunk q of the row-major tile lives in this LDS chunk
+    if constexpr (tile_rotated<NP>()) {
+        constexpr int CPR = NP / 2;
+        const int row = q / CPR, p = q - row * CPR, s = p + tile_rot<NP>(row);
+        return row * CPR + (s >= CPR ? s - CPR : s);
+    } else {
+        return q;
+    }
+}
+
 // Tried and rejected for balancing ACROSS CUs (a few CUs finish ~10 % late): tile tickets from
 // global atomic counters.  One counter retires only ~88 atomics/us (the kernels consume ~300
 // tiles/us); eight per-XCD counters with the ticket taken one or two iterations ahead still

@@ -27,6 +27,9 @@
 // MODE 2 ('e,ij,ej->ei': out[e,i] = J[e] sum_j D[i,j] u[e,j], tuning/impls/
 // e_ij_ej_to_ei_no_prftch.py:30-38) and MODE 3 ('ij,ej->ei', tuning/impls/ij_ej_to_ei_no_prftch.py)
 // are the same with ONE operator component (NC = 1): B fragment = J[e] u[e,j], or u[e,j] itself.
+// MODE 5 is MODE 4 over separate geometry-factor arrays and output planes (GradFields of fe_grad.h): the rows of a
+// batched 're,rij,ej->ei' that share u and D, at p = 5 (fe_gradplanes3d_f64; the cross-product batch of
+// tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231 forms D u once per field instead of once per row).
 // MODE 4 is grad 'xre,rij,ej->xei' BY COMPONENTS: the ND products D_r u keep separate accumulators
 // (same B fragment u for every r) and the epilogue contracts them with J[x, r, e], which is
 // lane-local because every r has the same (row, element) accumulator layout.  It costs ND
@@ -54,10 +57,11 @@ template <int NP, int M, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = 
 struct DivGeom {
     static constexpr int TEL = 16 * M;
     static constexpr int NPLANES = MODE == 0 ? ND : 1;  // u planes per tile
-    static constexpr int NC = (MODE == 0 || MODE == 4) ? ND : MODE == 1 ? 3 : 1;   // operator components r
-    static constexpr int NJ = (MODE == 0 || MODE == 4) ? ND * ND : MODE == 1 ? 3 : MODE == 2 ? 1 : 0;   // J values per element
-    static constexpr int NBF = MODE == 4 ? 1 : NC;      // distinct B fragments per k-quad
-    static constexpr int NOUT = MODE == 4 ? ND : 1;     // output planes
+    static constexpr bool BYCOMP = MODE == 4 || MODE == 5;   // grad by components (5: separate J arrays / output planes)
+    static constexpr int NC = (MODE == 0 || BYCOMP || MODE == 1) ? ND : 1;   // operator components r
+    static constexpr int NJ = (MODE == 0 || BYCOMP) ? ND * ND : MODE == 1 ? ND : MODE == 2 ? 1 : 0;   // J values per element
+    static constexpr int NBF = BYCOMP ? 1 : NC;         // distinct B fragments per k-quad
+    static constexpr int NOUT = BYCOMP ? ND : 1;        // output planes
     static constexpr int KSJ = (NP + 3) / 4;            // j quads; k-steps = NC KSJ, ordered (jq, r)
     static constexpr int BT = NP / 16;                  // 16-row tiles
     static constexpr int NR = NP - 16 * BT;             // rows left for the 4x4x4 groups
@@ -73,7 +77,8 @@ struct DivGeom {
     // and a separate o buffer resident (86 + 29 KB for four waves at Np = 56) there is no room for
     // the fragments.
     static constexpr bool STREAM = ALDS && MODE == 0;
-    static_assert(!W8 || (ALDS && MODE == 4 && M == 1), "eight-wave blocks: grad by components, A in LDS");
+    static_assert(!W8 || (ALDS && BYCOMP && M == 1), "eight-wave blocks: grad by components, A in LDS");
+    static_assert(MODE != 5 || (W8 && ND == 3), "grad planes by components: the eight-wave p = 5 kernel");
     struct WaveLds {
         double u[STREAM ? 2 : NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
         double o[(STREAM || W8) ? 2 : SUB_D];      // output transposition buffer (one 16-element sub-tile)
@@ -100,7 +105,8 @@ struct DivGeom {
 template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, const FieldPtrs& P,
-    int nb, int64_t E, int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk) {
+    int nb, int64_t E, int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk,
+    const GradFields* __restrict__ Q = nullptr) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
@@ -160,7 +166,15 @@ __device__ __forceinline__ void div3d_mfma_body(
             if (MODE == 0 && ND == 3) div3d_item(J, D, uk, ok, E, NP, e, i, opT);
             else if (MODE == 0) div_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
             else if (MODE == 4) grad_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
-            else if (MODE == 1) divcomp3d_item(J, D, uk, ok, E, NP, e, i, opT, jes);
+            else if (MODE == 5) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    double* ox = grad_plane_out(*Q, k, x);
+                    if (ox) divcomp3d_item(Q->j[x], D, uk, ox, E, NP, e, i, opT, 0);
+                }
+            }
+            else if (MODE == 1 && ND == 3) divcomp3d_item(J, D, uk, ok, E, NP, e, i, opT, jes);
+            else if (MODE == 1) divcomp_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT, jes);
             else matapply_item(MODE == 2 ? J : nullptr, D, uk, ok, NP, e, i, opT);
         }
     });
@@ -173,14 +187,14 @@ __device__ __forceinline__ void div3d_mfma_body(
     // tile and stays in LDS until the last field's B fragments are built.
     auto issue_loads = [&](int64_t tile, int fk, bool with_j) {
         const int64_t e0 = tile * G::TEL;
-        const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8) + lane * 16;
+        const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);
 #pragma unroll
         for (int x = 0; x < G::NPLANES; ++x) {
             const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
             for (int c = 0; c < G::P_INSTR; ++c)
                 if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
-                    glds16_nt(up + c * 1024, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+                    glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
         }
         if (!with_j) return;
         const char* jb = reinterpret_cast<const char*>(J) + e0 * 8;
@@ -188,8 +202,15 @@ __device__ __forceinline__ void div3d_mfma_body(
         for (int c = 0; c < G::J_INSTR; ++c) {
             const int q = c * 64 + lane;
             const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
-            // rows of E doubles; MODE 1 with J stored [E][3]: one contiguous span of 3 TEL doubles
-            const char* src = (MODE == 1 && jes) ? jb + e0 * 16 + q * 16 : jb + ((int64_t)row * E) * 8 + col * 16;
+            // rows of E doubles; MODE 1 with J stored [E][ND]: one contiguous span of ND TEL doubles
+            const char* src;
+            if constexpr (MODE == 5) {   // row = x ND + r of the x-th geometry-factor array
+                const int x = row / ND, r = row - ND * x;
+                src = reinterpret_cast<const char*>((x == 0 ? Q->j[0] : x == 1 ? Q->j[1] : Q->j[2]) + (int64_t)r * E + e0) +
+                      col * 16;
+            } else {
+                src = (MODE == 1 && jes) ? jb + e0 * (8 * (ND - 1)) + q * 16 : jb + ((int64_t)row * E) * 8 + col * 16;
+            }
             if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
         }
     };
@@ -199,11 +220,11 @@ __device__ __forceinline__ void div3d_mfma_body(
         //   L(p0), L(J) | L(p1) -> B += plane 0 | L(p2) -> B += plane 1 -> B += plane 2 | L(p0', J') | MFMAs | stores
         const unsigned lds_a = lds_addr_uniform(L->u[0]), lds_b = lds_addr_uniform(L->u[1]);
         auto issue_plane = [&](int64_t t, int fk, int x, unsigned lds) {
-            const char* up = reinterpret_cast<const char*>(field_in(P, fk)) + ((int64_t)x * E + t * G::TEL) * (NP * 8) +
-                             lane * 16;
+            const char* up = reinterpret_cast<const char*>(field_in(P, fk)) + ((int64_t)x * E + t * G::TEL) * (NP * 8);
 #pragma unroll
             for (int c = 0; c < G::P_INSTR; ++c)
-                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS) glds16_nt(up + c * 1024, lds + c * 1024);
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                    glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds + c * 1024);
         };
         auto issue_j = [&](int64_t t) {
             const char* jb = reinterpret_cast<const char*>(J) + t * G::TEL * 8;
@@ -236,7 +257,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq) {
                     const int j = 4 * jq + g;
-                    const double v = j < NP ? up[n * NP + (j < NP ? j : 0)] : 0.0;
+                    const double v = j < NP ? up[tile_index<NP>(n, j < NP ? j : 0)] : 0.0;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) bfrag[jq][r] = x == 0 ? jac[r] * v : bfrag[jq][r] + jac[x * 3 + r] * v;
                 }
@@ -276,11 +297,11 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int t = 0; t < G::BT; ++t)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+                for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) {
                 const int i = 16 * G::BT + 4 * q + g;
-                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
             }
             wave_lds_fence();
             double* op = out + tile * G::TEL * NP;
@@ -288,7 +309,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int c = 0; c < G::SUB_INSTR; ++c) {
                 const int qc = c * 64 + lane;
-                held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) ? *reinterpret_cast<const v2d*>(ob + 2 * qc)
+                held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc))
                                                                               : v2d{0.0, 0.0};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // o is in registers before buffer b is refilled
@@ -321,7 +342,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
                 const int j = 4 * jq + g;
-                bf[jq] = j < NP ? L->u[0][n * NP + (j < NP ? j : 0)] : 0.0;
+                bf[jq] = j < NP ? L->u[0][tile_index<NP>(n, j < NP ? j : 0)] : 0.0;
             }
             v4d acc[NC][G::BT > 0 ? G::BT : 1];
             double accs[NC][G::NS > 0 ? G::NS : 1];
@@ -347,6 +368,11 @@ __device__ __forceinline__ void div3d_mfma_body(
             double* ob = L->u[0];   // every B value is in a register by now (the MFMAs consumed them)
 #pragma unroll
             for (int x = 0; x < ND; ++x) {
+                double* plane = nullptr;
+                if constexpr (MODE == 5) {
+                    plane = grad_plane_out(*Q, fk, x);
+                    if (plane == nullptr) continue;   // plane not asked for (wave-uniform)
+                }
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t)
 #pragma unroll
@@ -354,7 +380,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                         double v = jk[x * ND] * acc[0][t][qq];
 #pragma unroll
                         for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * acc[r][t][qq];
-                        ob[n * NP + 16 * t + g + 4 * qq] = v;
+                        ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = v;
                     }
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) {
@@ -362,16 +388,16 @@ __device__ __forceinline__ void div3d_mfma_body(
                     double v = jk[x * ND] * accs[0][q];
 #pragma unroll
                     for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * accs[r][q];
-                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = v;
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = v;
                 }
                 wave_lds_fence();
-                double* op = out + ((int64_t)x * E + tile * G::TEL) * NP;
+                double* op = MODE == 5 ? plane + tile * G::TEL * NP : out + ((int64_t)x * E + tile * G::TEL) * NP;
                 v2d held[G::SUB_INSTR];
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
                     held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
-                                  ? *reinterpret_cast<const v2d*>(ob + 2 * qc) : v2d{0.0, 0.0};
+                                  ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc)) : v2d{0.0, 0.0};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // plane x has left the buffer
 #pragma unroll
@@ -437,7 +463,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             double jac[G::NJ > 0 ? G::NJ : 1];
 #pragma unroll
             for (int k = 0; k < G::NJ; ++k)   // jac[x*ND + r]  (MODE 1: jac[s]; MODE 2: jac[0] = J[e])
-                jac[k] = (MODE == 1 && jes) ? L->j[(16 * m + n) * 3 + k] : L->j[k * G::TEL + 16 * m + n];
+                jac[k] = (MODE == 1 && jes) ? L->j[(16 * m + n) * ND + k] : L->j[k * G::TEL + 16 * m + n];
             if (G::NJ == 0) jac[0] = 1.0;
             if (MODE == 4) {
 #pragma unroll
@@ -449,7 +475,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                 const int jc = j < NP ? j : 0;
                 double ux[G::NPLANES];
 #pragma unroll
-                for (int x = 0; x < G::NPLANES; ++x) ux[x] = j < NP ? L->u[x][(16 * m + n) * NP + jc] : 0.0;
+                for (int x = 0; x < G::NPLANES; ++x) ux[x] = j < NP ? L->u[x][tile_index<NP>(16 * m + n, jc)] : 0.0;
 #pragma unroll
                 for (int r = 0; r < G::NBF; ++r) {
                     if (MODE == 3 || MODE == 4) {
@@ -514,7 +540,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                             double v = jkeep[m][x * ND] * acc[0][t][qq];
 #pragma unroll
                             for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * acc[r][t][qq];
-                            ob[n * NP + 16 * t + g + 4 * qq] = v;
+                            ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = v;
                         }
 #pragma unroll
                     for (int q = 0; q < G::NS; ++q) {
@@ -522,7 +548,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                         double v = jkeep[m][x * ND] * accs[0][q];
 #pragma unroll
                         for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * accs[r][q];
-                        if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = v;
+                        if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = v;
                     }
                     wave_lds_fence();
                     double* op = out + ((int64_t)x * E + e0 + 16 * m) * NP;
@@ -530,7 +556,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     for (int c = 0; c < G::SUB_INSTR; ++c) {
                         const int qc = c * 64 + lane;
                         if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
-                            const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                            const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc));
                             __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
                         }
                     }
@@ -582,11 +608,11 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
             for (int t = 0; t < G::BT; ++t)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+                for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) {
                 const int i = 16 * G::BT + 4 * q + g;
-                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
             }
             wave_lds_fence();
             double* op = out + (e0 + 16 * m) * NP;
@@ -594,7 +620,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             for (int c = 0; c < G::SUB_INSTR; ++c) {
                 const int qc = c * 64 + lane;
                 if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
-                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc));
                     if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * qc] = val[1]; }
                     else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
                 }
@@ -612,6 +638,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void div3d_mfma_kernel(
     int64_t E, int64_t nTiles, int opT, int jes) {
     div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8, kPrep>(J, D, prep, P, nb, E, nTiles, opT, jes, blockIdx.x,
                                                             gridDim.x);
+}
+
+// grad-type planes at p = 5 (MODE 5): the fields' u pointers travel in P.v, everything else in Q
+template <int NP>
+__global__ __launch_bounds__(512, 1) void gradplanes_bycomp_kernel(GradFields Q, const double* __restrict__ D, FieldPtrs P,
+                                                                  int nb, int64_t E, int64_t nTiles, int opT) {
+    div3d_mfma_body<NP, 1, 0, 5, 3, true, true>(nullptr, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, &Q);
 }
 
 // The div sections of a prepared operator (plain div of tetrahedra): big-tile fragment

@@ -232,11 +232,11 @@ __device__ __forceinline__ void facemass_mfma_body(
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t)
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+                    for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) {
                     const int i = 16 * G::BT + 4 * q + g;
-                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
                 }
                 wave_lds_fence();
                 double* op = P.out[k] + tile * G::TEL * NP;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
                     held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
-                                  ? *reinterpret_cast<const v2d*>(ob + 2 * qc) : v2d{0.0, 0.0};
+                                  ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc)) : v2d{0.0, 0.0};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // o has left the buffer
 #pragma unroll
@@ -350,11 +350,11 @@ __device__ __forceinline__ void facemass_mfma_body(
 #pragma unroll
                 for (int t = 0; t < G::BT; ++t)
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) ob[n * NP + 16 * t + g + 4 * qq] = acc[t][qq];
+                    for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) {
                     const int i = 16 * G::BT + 4 * q + g;
-                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[n * NP + i] = accs[q];
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
                 }
                 wave_lds_fence();
                 double* op = P.out[k] + (tile * G::TEL + 16 * m) * NP;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
                     if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
-                        const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                        const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc));
                         __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
                     }
                 }

@@ -89,6 +89,23 @@ __device__ __forceinline__ void divcomp3d_item(const double* __restrict__ J, con
     out[e * Np + i] = acc;
 }
 
+// the same for ND-dimensional elements (ND = 2: triangles): J [ND][E] or [E][ND], D [ND][Np][Np]
+__device__ __forceinline__ void divcomp_nd_item(const double* __restrict__ J, const double* __restrict__ D,
+                                                const double* __restrict__ u, double* __restrict__ out, int64_t E,
+                                                int Np, int nd, int64_t e, int i, int opT, int jes) {
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+    const double* ue = u + e * Np;
+    double acc = 0.0;
+    for (int s = 0; s < nd; ++s) {
+        const double js = jes ? J[e * nd + s] : J[(int64_t)s * E + e];
+        const double* d = D + (int64_t)s * Np * Np + (int64_t)i * si;
+        double t = 0.0;
+        for (int j = 0; j < Np; ++j) t += d[j * sj] * ue[j];
+        acc += js * t;
+    }
+    out[e * Np + i] = acc;
+}
+
 __global__ __launch_bounds__(256) void divcomp3d_generic_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const double* __restrict__ u,
     double* __restrict__ out, int64_t E, int Np, int64_t e_begin, int opT, int jes) {

@@ -52,7 +52,7 @@ inline int64_t tiled_plan(TiledArgs& a) {
     a.ncomp = a.family == FE_FAMILY_GRAD ? a.ndim : 1;
     a.K = a.family == FE_FAMILY_GRAD || a.family == FE_FAMILY_MATAPPLY ? a.Np
         : a.family == FE_FAMILY_DIV ? a.ndim * a.Np
-        : a.family == FE_FAMILY_DIVCOMP ? 3 * a.Np
+        : a.family == FE_FAMILY_DIVCOMP ? a.ndim * a.Np
                                         : a.nf * a.Nfp;
     a.KP = a.K | 1;   // odd row stride: the element groups of a wave hit different banks
     // lanes per element group: grad keeps row i of all components, the others three rows each
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                     } else {
                         const double ue = live ? in[(e0 + e) * Np + j] : 0.0;
                         if (a.family == FE_FAMILY_DIVCOMP) {
-                            for (int s = 0; s < 3; ++s) {
-                                const double js = !live ? 0.0 : a.jlayout ? a.J[(e0 + e) * 3 + s] : a.J[(int64_t)s * E + e0 + e];
+                            for (int s = 0; s < nd; ++s) {
+                                const double js = !live ? 0.0 : a.jlayout ? a.J[(e0 + e) * nd + s] : a.J[(int64_t)s * E + e0 + e];
                                 Bt[e * KP + s * Np + j] = js * ue;
                             }
                         } else if (a.family == FE_FAMILY_MATAPPLY) {

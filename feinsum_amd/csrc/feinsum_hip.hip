@@ -145,6 +145,27 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
     return FE_OK;
 }
 
+// grad-type planes of tetrahedra p = 5 (MODE 5 of the div template): D u once per field, eight waves per block
+int launch_gradplanes_p5(const fe::GradFields& Q, const double* D, int nb, int64_t E, int opT, hipStream_t s,
+                         bool* launched) {
+    using G = fe::DivGeom<56, 1, 5, 3, true, true>;
+    const int64_t nTiles = E / G::TEL;
+    *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
+    if (nTiles == 0) return FE_OK;
+    static PerDeviceOnce once;
+    const int attr_rc = once.run([] {
+        return configure_kernel(fe::gradplanes_bycomp_kernel<56>, "grad planes p5 (components, A in LDS)", G::LDS_BYTES,
+                                G::THREADS, G::BLOCKS_PER_CU);
+    });
+    if (attr_rc != FE_OK) return attr_rc;
+    fe::FieldPtrs P = {};
+    for (int k = 0; k < nb; ++k) P.v[k] = Q.u[k];
+    const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
+    hipLaunchKernelGGL(fe::gradplanes_bycomp_kernel<56>, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(G::THREADS),
+                       G::LDS_BYTES, s, Q, D, P, nb, E, nTiles, opT);
+    return FE_OK;
+}
+
 // div of tetrahedra p = 5: the A fragments in LDS and the u planes streamed through two buffers
 int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
                   hipStream_t s, bool* launched) {
@@ -582,7 +603,7 @@ int launch_waveop(fe::WaveOpArgs a, const fe::GradFields& Pg, const fe::FieldPtr
 // triangles (ND = 2): grad by components (MODE 4) and div (MODE 0) instances of the div template
 template <int NP, int M, int MODE>
 int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
-               hipStream_t s, bool* launched) {
+               hipStream_t s, bool* launched, int jes = 0) {
     using G = fe::DivGeom<NP, M, MODE, 2>;
     const int64_t nTiles = E / G::TEL;
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
@@ -590,24 +611,24 @@ int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
         char what[64];
-        snprintf(what, sizeof(what), "triangles %s Np=%d M=%d", MODE == 4 ? "grad" : "div", NP, M);
+        snprintf(what, sizeof(what), "triangles %s Np=%d M=%d", MODE == 4 ? "grad" : MODE == 1 ? "div component" : "div", NP, M);
         return configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
     });
     if (attr_rc != FE_OK) return attr_rc;
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
-                       G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
+                       G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, jes);
     return FE_OK;
 }
 
 template <int MODE>
 int launch_nd2_np(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int Np, int opT,
-                  hipStream_t s, bool* launched) {
+                  hipStream_t s, bool* launched, int jes = 0) {
     switch (Np) {   // triangles p = 1..5; a wave tile of 16 M elements moves a few KB
-        case 21: return launch_nd2<21, (MODE == 0 ? 2 : 3), MODE>(J, D, P, nb, E, opT, s, launched);
-        case 15: return launch_nd2<15, 4, MODE>(J, D, P, nb, E, opT, s, launched);
-        case 10: return launch_nd2<10, 6, MODE>(J, D, P, nb, E, opT, s, launched);
-        case 6: return launch_nd2<6, 8, MODE>(J, D, P, nb, E, opT, s, launched);
-        default: return launch_nd2<3, 8, MODE>(J, D, P, nb, E, opT, s, launched);
+        case 21: return launch_nd2<21, (MODE == 0 ? 2 : 3), MODE>(J, D, P, nb, E, opT, s, launched, jes);
+        case 15: return launch_nd2<15, 4, MODE>(J, D, P, nb, E, opT, s, launched, jes);
+        case 10: return launch_nd2<10, 6, MODE>(J, D, P, nb, E, opT, s, launched, jes);
+        case 6: return launch_nd2<6, 8, MODE>(J, D, P, nb, E, opT, s, launched, jes);
+        default: return launch_nd2<3, 8, MODE>(J, D, P, nb, E, opT, s, launched, jes);
     }
 }
 
@@ -868,6 +889,16 @@ int fe_gradplanes3d_f64(const double* const* J3, const double* D, const double* 
     // plane through the div-component launcher, which has its own MFMA (p = 5), tiled and generic paths.
     const bool planes_kernel = (Np == 35 || Np == 20 || Np == 10 || Np == 4) &&
                                (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA);
+    if (Np == 56 && (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA)) {   // p = 5: grad by components
+        bool launched = false;
+        if (int rc = launch_gradplanes_p5(P, D, b, E, (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, static_cast<hipStream_t>(stream),
+                                          &launched))
+            return rc;
+        if (launched) {
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
+    }
     if (!planes_kernel) {
         for (int k = 0; k < b; ++k)
             for (int x = 0; x < 3; ++x)
@@ -1013,6 +1044,36 @@ int fe_div_f64(const double* J, const double* D, const double* const* u, double*
                int32_t ndim, int32_t Np, int32_t b, int32_t op_flags, int32_t variant, void* stream) {
     if (ndim == 3) return fe_div3d_batched_f64(J, D, u, out, E, Np, b, op_flags, variant, stream);
     return nd_launch(FE_FAMILY_DIV, "div", J, D, u, out, E, ndim, Np, b, op_flags, variant, stream);
+}
+
+int fe_divcomp_f64(const double* J, const double* D, const double* u, double* out, int64_t E, int32_t ndim,
+                   int32_t Np, int32_t op_flags, int32_t variant, void* stream) {
+    if (ndim == 3) return fe_divcomp3d_f64(J, D, u, out, E, Np, op_flags, variant, stream);
+    if (ndim != 2) return fail(FE_EUNSUPPORTED, "div component: ndim must be 2 or 3 (got %d)", ndim);
+    if (int rc = check_common(J, D, u, out, E, Np)) return rc;
+    if (op_flags & ~(FE_OP_TRANSPOSED | FE_OP_J_ES))
+        return fail(FE_EINVAL, "div component: bad operator flags %d", op_flags);
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED || variant == FE_VARIANT_GENERIC)
+        return fail(FE_EUNSUPPORTED, "div component: ndim = 2 has the MFMA and the tiled kernels (variant %d)", variant);
+    if (E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0, jes = (op_flags & FE_OP_J_ES) ? 1 : 0;
+    const bool mfma_ok = Np == 3 || Np == 6 || Np == 10 || Np == 15 || Np == 21;
+    fe::FieldPtrs P = {};
+    P.v[0] = u;
+    P.out[0] = out;
+    const fe::TiledArgs ta = tiled_args(FE_FAMILY_DIVCOMP, J, D, P, 1, E, 2, Np, 0, 0, opT, jes, 0);
+    KernelPath path;
+    if (int rc = choose_path(variant, mfma_ok, tiled_fits(ta), "div component", Np, &path)) return rc;
+    bool launched = false;
+    if (path == kPathMfma)
+        if (int rc = launch_nd2_np<1>(J, D, P, 1, E, Np, opT, s, &launched, jes)) return rc;
+    if (!launched) {   // no MFMA geometry, or fewer elements than one wave tile
+        if (!tiled_fits(ta)) return fail(FE_EUNSUPPORTED, "div component: no kernel for ndim = 2, Np = %d", Np);
+        if (int rc = launch_tiled(ta, s)) return rc;
+    }
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
 }
 
 int fe_divcomp3d_f64(const double* J, const double* D, const double* u, double* out, int64_t E,
@@ -1454,7 +1515,8 @@ static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
             return fe_graddiv3d_prepared_f64(a->J, a->D, a->prepared, a->u, a->v_div, a->out, a->out2, a->E, a->Np,
                                              a->variant, stream);
         case FE_FAMILY_DIVCOMP:
-            return fe_divcomp3d_f64(a->J, a->D, a->u, a->out, a->E, a->Np, a->layout_flags, a->variant, stream);
+            return fe_divcomp_f64(a->J, a->D, a->u, a->out, a->E, a->ndim == 2 ? 2 : 3, a->Np, a->layout_flags, a->variant,
+                                  stream);
         case FE_FAMILY_FACEMASS:
             return fe_facemass_prepared_f64(a->J, a->D, a->prepared, a->v, a->outs, a->E, a->Np, a->nf, a->Nfp, a->b,
                                             a->layout_flags, a->variant, stream);

@@ -127,9 +127,9 @@ def match_family(einsum: BatchedEinsum) -> Optional[KernelPlan]:
                 continue
             params = {"Np": int(dim("i")), "ndim": int(dim("x"))}
         elif family == FAMILY_DIVCOMP:
-            if int(dim("r")) != 3 or int(dim("i")) != int(dim("j")):
+            if int(dim("r")) not in (2, 3) or int(dim("i")) != int(dim("j")):
                 continue
-            params = {"Np": int(dim("i"))}
+            params = {"Np": int(dim("i")), "ndim": int(dim("r"))}
         elif family == FAMILY_MATAPPLY:
             if int(dim("i")) != int(dim("j")):
                 continue

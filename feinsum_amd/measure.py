@@ -301,7 +301,7 @@ class _FamilyLaunch:
         ``tuning/impls/re_rji_ej_to_ei_3d_cross_product_v0.py:220-231``) go through the grad-type
         planes launch, which forms D u once per field.  False: keep one launch per row."""
         role, rows = self.plan.roles, einsum.args
-        if self.plan.layout_flags & OP_J_ES:
+        if self.plan.layout_flags & OP_J_ES or self.plan.params.get("ndim", 3) != 3:
             return False
         if len({row[role["D"]].name for row in rows}) != 1:
             return False
@@ -350,8 +350,8 @@ class _FamilyLaunch:
                 _hip.check(lib.fe_matapply_f64(pack.J, pack.D, pack.v, pack.outs, pack.E, pack.Np, pack.b,
                                                pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_DIVCOMP:
-                _hip.check(lib.fe_divcomp3d_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.Np,
-                                                pack.layout_flags, pack.variant, stream_ptr))
+                _hip.check(lib.fe_divcomp_f64(pack.J, pack.D, pack.u, pack.out, pack.E, pack.ndim, pack.Np,
+                                              pack.layout_flags, pack.variant, stream_ptr))
             else:
                 _hip.check(lib.fe_facemass_prepared_f64(pack.J, pack.D, pack.prepared, pack.v, pack.outs, pack.E,
                                                         pack.Np, pack.nf, pack.Nfp, pack.b, pack.layout_flags,

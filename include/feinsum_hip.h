@@ -118,6 +118,12 @@ int fe_divcomp3d_f64(const double* J, const double* D, const double* u,
                      double* out, int64_t E, int32_t Np, int32_t op_flags,
                      int32_t variant, void* stream);
 
+/* The same for ndim-dimensional simplices (ndim = 3 is fe_divcomp3d_f64; ndim = 2, triangles:
+ * J [2][E] or [E][2], D [2][Np][Np]; MFMA kernels for Np in {3, 6, 10, 15, 21}, else the tiled kernel). */
+int fe_divcomp_f64(const double* J, const double* D, const double* u,
+                   double* out, int64_t E, int32_t ndim, int32_t Np, int32_t op_flags,
+                   int32_t variant, void* stream);
+
 /* div:   out[e,i] = sum_{x,r,j} J[x,r,e] * D[r,i,j] * u[x,e,j]
  * 'xre,rij,xej->ei' (tuning/impls/xre_rij_xej_to_ei.py:26-60).
  *   J [3][3][E]   D [3][Np][Np]   u [3][E][Np]   out [E][Np]                */

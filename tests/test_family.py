@@ -94,10 +94,12 @@ def test_transposed_operator_siblings():
 def test_div_component_family():
     # test/test_codegen.py:34-66 'se, sij, ej -> ei' x 3, and the 'es' layout of examples/dg_wave_div.py
     p = f.match_family(dg.batched_div_components())
-    assert p.family == FAMILY_DIVCOMP and p.layout_flags == 0 and p.params == {"Np": 35}
+    assert p.family == FAMILY_DIVCOMP and p.layout_flags == 0 and p.params == {"Np": 35, "ndim": 3}
     es = f.batched_einsum("es,sij,ej->ei", [[f.array("J" + c, ("E", 3)), f.array("R", (3, 35, 35)),
                                              f.array("u" + c, ("E", 35))] for c in "xyz"])
     assert f.match_family(es).layout_flags == 2
-    # 2D (s = 2) is not the 3D kernel
+    # triangles (s = 2) are the same family with ndim = 2; other component counts are not DG einsums
     e2 = f.einsum("se,sij,ej->ei", f.array("J", (2, "E")), f.array("R", (2, 10, 10)), f.array("u", ("E", 10)))
-    assert f.match_family(e2) is None
+    assert f.match_family(e2).params == {"Np": 10, "ndim": 2}
+    e4 = f.einsum("se,sij,ej->ei", f.array("J", (4, "E")), f.array("R", (4, 10, 10)), f.array("u", ("E", 10)))
+    assert f.match_family(e4) is None

@@ -330,7 +330,13 @@ def test_two_dimensional_operators(torch_cuda, Np, Nfp, E):
                                                   f2.array(f"v{k}", (3, "E", Nfp))] for k in range(3)])
     bgrad2 = f2.batched_einsum("xre,rji,ej->xei", [[f2.array("J", (2, 2, "E")), f2.array("R", (2, Np, Np)),
                                                     f2.array(f"u{k}", ("E", Np))] for k in range(3)])
-    for expr in (grad2, div2, lift2, bgrad2):
+    # div components of triangles ('se,sij,ej->ei' with two components; tuning/impls/re_rij_ej_to_ei.py with ndim = 2),
+    # in both J layouts and with the transposed operator
+    comp2 = f2.batched_einsum("se,sij,ej->ei", [[f2.array("J" + c, (2, "E")), f2.array("R", (2, Np, Np)),
+                                                f2.array("u" + c, ("E", Np))] for c in "xy"])
+    comp2_es = f2.batched_einsum("es,sji,ej->ei", [[f2.array("J" + c, ("E", 2)), f2.array("R", (2, Np, Np)),
+                                                   f2.array("u" + c, ("E", Np))] for c in "xy"])
+    for expr in (grad2, div2, lift2, bgrad2, comp2, comp2_es):
         assert f2.match_family(expr) is not None
         host = generate_host_input_arrays(expr, E, np_seed=Np)
         ref = _oracle(expr, host)

@@ -32,8 +32,7 @@ def main() -> None:
     for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
         exprs += [dg.grad(Np), dg.div(Np), dg.batched_div_components(Np), dg.face_mass(4, Np=Np, Nfp=Nfp),
                   dg.face_mass(2, Np=Np, Nfp=Nfp), dg.mass_apply(2, Np), dg.operator_apply(Np)]
-        if Np != 56:
-            exprs.append(dg.cross_product_batch(Np))
+        exprs.append(dg.cross_product_batch(Np))
     exprs += [dg.grad(84)]                                    # tiled kernel
     for expr in exprs:
         host = generate_host_input_arrays(expr, E)
