@@ -22,9 +22,10 @@ Argument conventions kept from the reference:
                exist in this build, so a callable (or ``None``) is ignored and
                selects the default kernel variant, while a ``str`` / ``dict``
                (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
-               a variant explicitly; ``{"prepared": False}`` makes a bound
-               launch (``timeit``, ``bind_operator``) rebuild its operator
-               fragments in every launch instead of using a prepared copy.
+               a variant explicitly; in a dict, ``"prepared": True`` lets a
+               bound launch (``timeit``) use a prepared copy of its operator
+               matrices and ``"placement": "tuned"`` makes ``timeit`` place the
+               arrays where the launch runs fastest (``feinsum_amd.placement``).
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -555,9 +556,34 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
         validate_batched_einsum_transform(einsum, q, transform, schedule)
     arg_dict = generate_input_arrays(q, einsum, long_dim_length)
     out_dict = generate_out_arrays(q, einsum, long_dim_length)
-    # one binding, many launches: the operator matrices are prepared once (see _FamilyLaunch.prepare_operators;
-    # `transform={"prepared": False}` times the launch that rebuilds its fragments from the plain arrays)
-    _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=True)
+    # `transform={"prepared": True}`: the operator matrices are written once in fragment layout (see
+    # _FamilyLaunch.prepare_operators) instead of being rebuilt by every launch
+    prepare = _prepared_from_transform(transform, False)
+    if isinstance(transform, Mapping) and transform.get("placement") == "tuned":
+        # the same arrays, moved into one arena at the position where the launch runs fastest (placement.py)
+        from feinsum_amd import placement
+
+        names = sorted(arg_dict)
+        arrays = [(n, tuple(arg_dict[n].shape), arg_dict[n].dtype) for n in names] \
+            + [(n, tuple(t.shape), t.dtype) for n, t in out_dict.items()]
+        staged = dict(arg_dict)
+
+        def fill(name, view):
+            if name in staged:
+                view.copy_(staged[name])
+            else:
+                view.zero_()
+
+        def make_step(views):
+            _, b, _ = _bind(einsum, q, {n: views[n] for n in names}, {n: views[n] for n in out_dict}, transform,
+                            prepare=prepare)
+            return lambda n: b.time_batch(n, q.stream_ptr)
+
+        with torch.cuda.device(q.torch_device):
+            arena, views, _report = placement.tune_base(arrays, q.torch_device, make_step, fill=fill)
+        arg_dict, out_dict = {n: views[n] for n in names}, {n: views[n] for n in out_dict}
+        del staged
+    _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=prepare)
     with torch.cuda.device(q.torch_device):
         for _ in range(N_WARMUP_ROUNDS):
             bound.launch(q.stream_ptr)

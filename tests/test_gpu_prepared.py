@@ -136,8 +136,11 @@ def test_buffers_that_do_not_fit_the_call_are_refused():
     torch.cuda.synchronize()
 
 
-def test_timeit_uses_prepared_operators_and_can_be_told_not_to():
+def test_timeit_options_prepared_and_tuned_placement():
     expr = dg.grad()
-    t_prep = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2)
-    t_plain = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2, transform={"prepared": False})
-    assert 0 < t_prep.seconds_device < 1e-3 and 0 < t_plain.seconds_device < 1e-3
+    t_plain = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2)
+    t_prep = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2, transform={"prepared": True})
+    t_tuned = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2,
+                                     transform={"variant": "mfma", "placement": "tuned"})
+    for t in (t_plain, t_prep, t_tuned):
+        assert 0 < t.seconds_device < 1e-3
