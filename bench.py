@@ -444,9 +444,9 @@ def main() -> None:
     if args.placement == "tuned":
         from feinsum_amd import placement
 
-        # every array of the workload, in layout order: per stage the inputs (sorted names; J and D of the grad / div
-        # pair once), then the outputs
-        arrays, seen = [], set()
+        # every array of the workload, in layout order: the inputs of all stages (sorted names; J and D of the grad /
+        # div pair once), then the outputs of all stages
+        arrays, outputs, seen = [], [], set()
         for k, expr in enumerate(exprs):
             for name in sorted(expr.all_args):
                 key = name if name in ("J", "R") else f"{k}:{name}"
@@ -455,7 +455,8 @@ def main() -> None:
                     shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[name])
                     arrays.append((key, shape, torch.float64))
             out_shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
-            arrays += [(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names]
+            outputs += [(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names]
+        arrays += outputs      # everything read first, everything written behind it (see placement.tune_base)
 
         def fill(key, view):
             if ">" in key:

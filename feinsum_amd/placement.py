@@ -139,7 +139,9 @@ def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
         ts = sorted(step(n) / n for _ in range(reps))
         return ts[len(ts) // 2] * 1e3
 
-    stride = max(length // 2 // ALIGN * ALIGN, 256 * MIB)
+    # the fast positions are plateaus about 1 GiB wide (the joint has to fall between the arrays read and the arrays
+    # written): steps of a quarter of the layout, at least 256 MiB and at most 1 GiB
+    stride = min(max(length // 4 // ALIGN * ALIGN, 256 * MIB), 1024 * MIB)
     coarse = {b: time_at(b, coarse_launches, 1) for b in range(0, last + 1, stride)}
     best = min(coarse, key=coarse.get)
     fine = {best: time_at(best, launches, rounds)}
