@@ -558,13 +558,13 @@ def main() -> None:
                             variant=args.variant, device_name=q.device.name, entry_points=op.entry_points,
                             extra=extra)
         rec, note = committed_counters(args.workload, E)
-        if rec is not None and not args.no_fuse:
+        if rec is not None and not args.no_fuse and not args.prepare:      # (the profiled kernels are the default ones)
             line["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
             line["roofline"]["traffic_source"] = {k: rec.get(k) for k in ("kernel", "source_sha", "profile", "E")}
             line["mfma_util"] = rec.get("mfma_util")
             line["mfma_util_source"] = rec.get("mfma_util_formula")
         else:
-            line["roofline"]["traffic_note"] = note or "PMC profile is of the fused launch"
+            line["roofline"]["traffic_note"] = note or "the committed PMC profile is of the default (fused, unprepared) launch"
             line["mfma_util"] = None
         if info.world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, full=args.cpu_baseline == "full")
