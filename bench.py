@@ -530,7 +530,7 @@ def main() -> None:
 
     # flops of the whole job = sum over ranks (ranks may hold different element counts)
     flops_all = flops_step
-    if info.world_size > 1:
+    if parallel.in_group():
         import torch.distributed as dist
 
         t = torch.tensor([flops_step], dtype=torch.float64,
@@ -543,7 +543,7 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
-                 "dist_backend": info.backend if info.world_size > 1 else None}
+                 "dist_backend": info.backend if parallel.in_group() else None}
         if protocol_ms is not None:
             extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)
             extra["protocol"] = {"what": "reference timing protocol (src/feinsum/measure.py:248-275): 5 warm-ups, "
@@ -570,7 +570,7 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(args.workload, full=args.cpu_baseline == "full")
         print(json.dumps(line), flush=True)
 
-    if info.world_size > 1:
+    if parallel.in_group():
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -87,7 +87,9 @@ def init_distributed(backend: str | None = None) -> DistInfo:
         backend = os.environ.get("FEINSUM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         local_rank %= max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # FEINSUM_DIST_FORCE=1 joins a group even at world size 1: every collective of the sharded path then runs through
+    # the backend (a one-GPU box can rehearse the RCCL calls themselves that way)
+    if world > 1 or os.environ.get("FEINSUM_DIST_FORCE") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -97,6 +99,13 @@ def init_distributed(backend: str | None = None) -> DistInfo:
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return DistInfo(rank, local_rank, world, backend)
+
+
+def in_group() -> bool:
+    """Has this process joined a process group (then the exchanges below are real collectives)?"""
+    import torch.distributed as dist
+
+    return bool(dist.is_available() and dist.is_initialized())
 
 
 def result_reduction(outs: Sequence[Any]) -> Any:
@@ -126,7 +135,7 @@ def allgather_reduction(local: Any) -> Any:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not in_group():
         return local.unsqueeze(0)
     send = _comm_tensor(local.contiguous())
     gathered = [torch.empty_like(send) for _ in range(dist.get_world_size())]
@@ -148,7 +157,7 @@ def allgather_field(local: Any, axis: int, sizes: Sequence[int]) -> Any:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not in_group():
         return local
     moved = local.movedim(axis, 0).contiguous()
     pad = max(sizes)
@@ -164,7 +173,7 @@ def allgather_field(local: Any, axis: int, sizes: Sequence[int]) -> Any:
 def barrier() -> None:
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if in_group():
         if dist.get_backend() == "nccl":
             import torch
 
@@ -177,7 +186,7 @@ def max_over_ranks(value: float, device: Any = None) -> float:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not in_group():
         return float(value)
     on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=on)

@@ -1,0 +1,52 @@
+"""
+bench.py end to end on the GPU box, as the driver starts it: the JSON line carries the contract's
+fields, and the sharded path's collectives run through RCCL itself (a one-GPU box joins a group of
+one: FEINSUM_DIST_FORCE=1), so the N > 1 launch cannot fail on the backend's calls.
+"""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+SMALL = ["--steps", "3", "--warmup", "1", "--setup-launches", "5", "--elems-per-gpu", "20000", "--no-cpu-baseline",
+         "--no-protocol", "--placement", "separate"]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "setup_launches"}
+
+
+def _json_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["grad", "pipeline"])
+def test_bench_line_single_process(workload):
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--workload", workload] + SMALL,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _json_line(out.stdout)
+    assert REQUIRED <= set(line), sorted(REQUIRED - set(line))
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["dtype"] == "f64" and line["result_finite"]
+    assert line["dist_backend"] is None and line["value"] > 0
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_collectives_through_rccl_in_a_group_of_one():
+    env = dict(os.environ, FEINSUM_DIST_FORCE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("FEINSUM_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "1", "--workload", "pipeline"] + SMALL
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _json_line(out.stdout)
+    assert line["dist_backend"] == "nccl" and line["n_gpus"] == 1 and line["result_finite"] and line["value"] > 0
+    assert line["result_allgather_ms"] >= 0.0

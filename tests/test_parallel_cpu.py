@@ -82,3 +82,30 @@ def test_two_rank_gloo_sharded_grad(tmp_path):
     full = np.load(tmp_path / "full.npy")
     np.testing.assert_array_equal(full, ref)             # shards are bit-identical slices
     np.testing.assert_allclose(total[0], [ref.sum(), (ref * ref).sum(), np.abs(ref).max()], rtol=1e-13)
+
+
+def test_group_of_one_runs_the_collectives():
+    """FEINSUM_DIST_FORCE=1: a single process joins a group and every exchange goes through the backend
+    (how a one-GPU box rehearses the RCCL calls; here with gloo)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, torch\n"
+        "from feinsum_amd import parallel\n"
+        "info = parallel.init_distributed()\n"
+        "assert parallel.in_group() and info.world_size == 1 and info.backend == 'gloo'\n"
+        "local = parallel.result_reduction([torch.arange(6, dtype=torch.float64).reshape(2, 3)])\n"
+        "g = parallel.allgather_reduction(local)\n"
+        "assert g.shape == (1, 1, 3) and torch.equal(parallel.combine_reductions(g), local)\n"
+        "parallel.barrier()\n"
+        "assert parallel.max_over_ranks(2.5) == 2.5\n"
+        "f = parallel.allgather_field(torch.ones(4, 3, dtype=torch.float64), 0, [4])\n"
+        "assert f.shape == (4, 3)\n"
+        "import torch.distributed as dist; dist.destroy_process_group()\n"
+        "print('ok')\n")
+    env = dict(os.environ, FEINSUM_DIST_FORCE="1", FEINSUM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29641", WORLD_SIZE="1", RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
