@@ -394,6 +394,9 @@ def main() -> None:
     ap.add_argument("--arena-gib", type=float, default=66.0, help="size of the placement arena (tuned placement)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
+    ap.add_argument("--gather-fields", choices=("auto", "on", "off"), default="auto",
+                    help="after the timed region: all-gather every output field over the ranks and report the rate "
+                         "(SURVEY 8e's optional full-field exchange; auto = when there is more than one rank)")
     args = ap.parse_args()
 
     import torch
@@ -528,6 +531,28 @@ def main() -> None:
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
 
+    # the optional full-field exchange (off the clock; never part of `value`): the one place xGMI carries data
+    field_gather = None
+    if parallel.in_group() and (args.gather_fields == "on" or (args.gather_fields == "auto" and info.world_size > 1)):
+        lengths = {E} if not args.elems_total else \
+            {b - a for a, b in (parallel.shard_bounds(args.elems_total, info.world_size, r) for r in range(info.world_size))}
+        if len(lengths) != 1:               # (every rank computes the same set: no rank enters the collective alone)
+            field_gather = {"skipped": "shards of unequal length"}
+        else:
+            try:
+                axes = [[i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
+                        for expr in exprs for _ in expr.output_names]
+                g = parallel.allgather_fields_timed(list(zip(outs_all, axes)), sync)
+                sums = g.pop("sums")
+                g["matches_reduction"] = bool(all(abs(a - float(b)) <= 1e-9 * max(1.0, abs(float(b)))
+                                                  for a, b in zip(sums, total[:, 0].tolist())))
+                g["ms"], g["gbps_per_gpu"] = round(g["ms"], 3), round(g["gbps_per_gpu"], 1)
+                g["backend"] = info.backend           # nccl = RCCL over xGMI; gloo (rehearsals) goes through host memory
+                g["xgmi_peak_gbps_per_gpu"] = 7 * 153.0
+                field_gather = g
+            except Exception as exc:      # an optional exchange must not cost the line
+                field_gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     # flops of the whole job = sum over ranks (ranks may hold different element counts)
     flops_all = flops_step
     if parallel.in_group():
@@ -543,7 +568,7 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
-                 "dist_backend": info.backend if parallel.in_group() else None}
+                 "dist_backend": info.backend if parallel.in_group() else None, "field_allgather": field_gather}
         if protocol_ms is not None:
             extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)
             extra["protocol"] = {"what": "reference timing protocol (src/feinsum/measure.py:248-275): 5 warm-ups, "

@@ -170,6 +170,42 @@ def allgather_field(local: Any, axis: int, sizes: Sequence[int]) -> Any:
     return full.movedim(0, axis).contiguous()
 
 
+def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict:
+    """
+    The optional full-field exchange of SURVEY section 8(e): every rank receives every other rank's shard of every
+    output (equal shard lengths; *fields* = ``[(local tensor, element axis)]``).  One ``all_gather_into_tensor`` per
+    field on RCCL (gloo: the list form through host memory); only the collectives are between the two fences, the
+    layout copy that brings the element axis to the front is not.  Returns the milliseconds, the bytes each GPU
+    received from the others, that rate in GB/s (to be read against 7 xGMI links x 153 GB/s) and ``sums`` = the sum of
+    every gathered field (the caller checks them against the all-gathered reductions).
+    """
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    if not in_group():
+        raise RuntimeError("allgather_fields_timed needs a process group")
+    world = dist.get_world_size()
+    staged = []
+    for local, axis in fields:
+        moved = _comm_tensor(local.movedim(axis, 0).contiguous())
+        staged.append((moved, torch.empty((world,) + tuple(moved.shape), dtype=moved.dtype, device=moved.device)))
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for moved, full in staged:
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(full, moved)
+        else:
+            dist.all_gather(list(full.unbind(0)), moved)
+    sync()
+    ms = (time.perf_counter() - t0) * 1e3
+    received = sum(moved.numel() * moved.element_size() for moved, _ in staged) * (world - 1)
+    return {"ms": ms, "bytes_received_per_gpu": received, "gbps_per_gpu": received / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0,
+            "sums": [float(full.sum().item()) for _, full in staged], "world_size": world}
+
+
 def barrier() -> None:
     import torch.distributed as dist
 

@@ -54,6 +54,10 @@ def _worker(rank, world, port, elems_total, elems_per_gpu, tmpdir):
     flops = float(f.count_ops(expr, long_dim_length=E))
     t = torch.tensor([flops], dtype=torch.float64)
     dist.all_reduce(t)
+    if not elems_total:  # equal shards: the optional full-field exchange
+        g = parallel.allgather_fields_timed([(torch.from_numpy(out), 1)], sync=lambda: None)
+        assert g["world_size"] == world and g["bytes_received_per_gpu"] == out.nbytes * (world - 1)
+        assert abs(g["sums"][0] - float(total[0, 0])) <= 1e-9 * abs(float(total[0, 0]))
     if rank == 0:
         line = bench.compose_line(workload="grad", n_gpus=world, steps=3, warmup=0, wall_s=wall_s, kernel_s=kernel_s,
                                   flops_step_all=float(t.item()) * 1e6, flops_step_rank0=flops * 1e6,   # (x 1e6: the line rounds to 0.1 GFLOP/s)

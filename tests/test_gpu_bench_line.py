@@ -44,9 +44,11 @@ def test_bench_collectives_through_rccl_in_a_group_of_one():
     env = dict(os.environ, FEINSUM_DIST_FORCE="1", MASTER_ADDR="127.0.0.1")
     env.pop("FEINSUM_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "1", "--workload", "pipeline"] + SMALL
+           "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "1", "--workload", "pipeline", "--gather-fields", "on"] + SMALL
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = _json_line(out.stdout)
     assert line["dist_backend"] == "nccl" and line["n_gpus"] == 1 and line["result_finite"] and line["value"] > 0
     assert line["result_allgather_ms"] >= 0.0
+    g = line["field_allgather"]           # six output fields through all_gather_into_tensor (a group of one receives nothing)
+    assert g["world_size"] == 1 and g["bytes_received_per_gpu"] == 0 and g["matches_reduction"], g
