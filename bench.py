@@ -449,7 +449,7 @@ def main() -> None:
 
         # every array of the workload, in layout order: the inputs of all stages (sorted names; J and D of the grad /
         # div pair once), then the outputs of all stages
-        arrays, outputs, seen = [], [], set()
+        arrays, outputs, seen = [], [], set()        # outputs: per stage
         for k, expr in enumerate(exprs):
             for name in sorted(expr.all_args):
                 key = name if name in ("J", "R") else f"{k}:{name}"
@@ -458,8 +458,10 @@ def main() -> None:
                     shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[name])
                     arrays.append((key, shape, torch.float64))
             out_shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
-            outputs += [(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names]
-        arrays += outputs      # everything read first, everything written behind it (see placement.tune_base)
+            outputs.append([(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names])
+        # everything read first, everything written behind it, ordered so that one boundary between two classes of
+        # physical memory splits the write streams of every stage
+        arrays += placement.split_order(outputs)
 
         def fill(key, view):
             if ">" in key:

@@ -102,6 +102,30 @@ def tune_gap(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
     return arena, views, report
 
 
+def split_order(stages: Sequence[Sequence[Tuple[str, Tuple[int, ...], Any]]]) -> List[Tuple[str, Tuple[int, ...], Any]]:
+    """
+    Layout order of the WRITTEN arrays of a (multi-stage) launch such that ONE cut through the layout splits the
+    concurrently written streams of every stage: of a stage that writes several arrays (face-mass x b) the first half
+    goes to the left and the second half to the right; a stage that writes one array of several planes (grad:
+    ``[3][E][Np]``) goes in the middle, where the cut can fall inside it; single-stream outputs (div) go to the left.
+    *stages*: per stage the ``(name, shape, dtype)`` of its outputs.
+    """
+    left: List[Any] = []
+    middle: List[Any] = []
+    right: List[Any] = []
+    for outs in stages:
+        outs = list(outs)
+        if len(outs) > 1:
+            half = (len(outs) + 1) // 2
+            left += outs[:half]
+            right += outs[half:]
+        elif outs and len(outs[0][1]) == 3 and outs[0][1][0] > 1:      # [planes][E][Np]: written plane by plane together
+            middle += outs
+        else:
+            left += outs
+    return left + middle + right
+
+
 def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
               make_step: Callable[[Dict[str, Any]], Callable[[int], float]], *,
               arena_gib: float = 66.0, gap_mib: int = 64, fill: Callable[[str, Any], None] | None = None,
@@ -139,14 +163,16 @@ def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
         ts = sorted(step(n) / n for _ in range(reps))
         return ts[len(ts) // 2] * 1e3
 
-    # the fast positions are plateaus about 1 GiB wide (the joint has to fall between the arrays read and the arrays
-    # written): steps of a quarter of the layout, at least 256 MiB and at most 1 GiB
+    # the launch is fast while the class boundary cuts through the written arrays (the plateau is as wide as one array /
+    # one plane, with linear ramps of the same width either side): coarse steps of a quarter of the layout, at least
+    # 256 MiB and at most 1 GiB, then the neighbourhood of the best position in steps of at most 128 MiB
     stride = min(max(length // 4 // ALIGN * ALIGN, 256 * MIB), 1024 * MIB)
     coarse = {b: time_at(b, coarse_launches, 1) for b in range(0, last + 1, stride)}
     best = min(coarse, key=coarse.get)
     fine = {best: time_at(best, launches, rounds)}
-    for frac in (-0.5, -0.25, 0.25, 0.5):
-        b = int(best + frac * stride) // ALIGN * ALIGN
+    step = max(64 * MIB, min(stride // 4, 128 * MIB)) // ALIGN * ALIGN
+    for k in range(-(stride // step), stride // step + 1):
+        b = (best + k * step) // ALIGN * ALIGN
         if 0 <= b <= last and b not in fine:
             fine[b] = time_at(b, launches, rounds)
     best = min(fine, key=fine.get)

@@ -20,6 +20,19 @@ def test_layout_offsets():
         assert offs[-1] + sizes[-1] <= placement.arena_bytes(sizes, 136 * MIB)
 
 
+def test_split_order_puts_one_cut_through_every_stage():
+    E = 1000
+    stages = [[("0>out", (E, 35), None)],                               # div: one stream
+              [("1>out", (3, E, 35), None)],                            # grad: three planes of one array
+              [(f"2>out{k}", (E, 35), None) for k in range(4)]]         # face-mass x 4: four arrays
+    names = [n for n, _, _ in placement.split_order(stages)]
+    assert names == ["0>out", "2>out0", "2>out1", "1>out", "2>out2", "2>out3"]
+    # a single stage keeps its order; three outputs split 2 + 1
+    assert [n for n, _, _ in placement.split_order([stages[2]])] == [f"2>out{k}" for k in range(4)]
+    assert [n for n, _, _ in placement.split_order([stages[2][:3]])] == ["2>out0", "2>out1", "2>out2"]
+    assert placement.split_order([]) == []
+
+
 @pytest.mark.gpu
 def test_tuned_layout_gives_the_same_results():
     import torch
