@@ -144,10 +144,11 @@ __device__ __forceinline__ void stage_operator_dma(const double* __restrict__ g,
 }
 
 // ---- prepared operators (fe_prepare_operator) -------------------------------------------------
-// An operator matrix is constant across the launches of a time-stepping code, while rebuilding its
-// MFMA A fragments in every launch is most of a launch's fixed cost (stage the matrix through LDS,
-// two block barriers, one dependent LDS gather per fragment: 5-9 us before the first tile of a
-// wave, half of a launch at E = 1e5).  A prepared operator is the same matrix written ONCE in
+// An operator matrix is constant across the launches of a time-stepping code, while every launch
+// rebuilds its MFMA A fragments (stage the matrix through LDS, two block barriers, one dependent LDS
+// gather per fragment: 3-9 us before a wave's first tile -- which, measured, overlaps the first
+// tiles' load latency, so that prepared operators do not shorten a launch: DESIGN.md section 3e).
+// A prepared operator is the same matrix written ONCE in
 // fragment layout: fragment f of lane l is double  ((f >> 1) * 64 + l) * 2 + (f & 1)  of its section,
 // so a wave fetches two fragments per 16-byte load, 1 KiB contiguous per wave-instruction (from L2
 // after the first wave of an XCD), with no LDS staging and no barrier.
