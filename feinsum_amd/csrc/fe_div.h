@@ -45,6 +45,12 @@
 
 namespace fe {
 
+#ifdef FE_EXPERIMENTS
+// Diagnostic build only: per wave of the eight-wave p = 5 kernels {shader cycles waiting for the tile, in the MFMA
+// phase, in the epilogue; tiles done; HW_ID; 100 MHz stamps of loop start and end}.
+__device__ unsigned long long fe_dbg_w8[4096][8];
+#endif
+
 // ALDS: the big-tile A fragments live in LDS (fragment layout, conflict-free 512-byte reads)
 // instead of registers.  At Np = 56 (tetrahedra p = 5) they are 126 doubles per lane -- the whole
 // register file -- while one fragment read per 64-cycle MFMA is only 6 % of the LDS bandwidth.
@@ -328,14 +334,42 @@ __device__ __forceinline__ void div3d_mfma_body(
     if constexpr (W8) {
         // ---- eight waves per block (see DivGeom): wait u, J -> B, J to registers -> MFMAs -> three
         //      planes through the (former u) buffer -> request the next unit
+        //      Tried (experiment build, kDbg 64 / 16; in-process A/B in tools/w8_phases.py): the wave in the even
+        //      hardware slot at raised priority with the block's tiles handed out by an LDS ticket counter (so that
+        //      the partners of a SIMD cannot fall into step), and the next unit requested ahead of the last plane's
+        //      stores -- 0.390-0.398 ms against 0.375-0.386 for this loop: neither helps.  The per-wave chain
+        //      load -> MFMAs -> three planes through the one buffer is what binds (p = 5).
+        constexpr bool kTicket = (kDbg & 64) != 0, kEarly = (kDbg & 16) != 0;
+        unsigned* const ticket = reinterpret_cast<unsigned*>(reinterpret_cast<WaveLds*>(smem)->o);   // (o is unused here)
+        if constexpr (kTicket) {
+            if (threadIdx.x == 0) *ticket = G::WAVES;           // tickets 0 .. W-1 are the waves' first tiles
+            __syncthreads();
+            if ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0) __builtin_amdgcn_s_setprio(2);   // HW_ID.WAVE_ID[0]
+        }
+        auto next_ticket_tile = [&]() -> int64_t {   // ticket t of block b is tile b W + t mod W + (t div W) stride
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = __builtin_amdgcn_readfirstlane(t);
+            return (int64_t)bid * G::WAVES + (t % G::WAVES) + (int64_t)(t / G::WAVES) * stride;
+        };
         int fk = 0;
-        if (tile < tEnd) issue_loads(tile, 0, true);
+#ifdef FE_EXPERIMENTS
+        unsigned long long dw = 0, dm = 0, de = 0, dn = 0;
+        const unsigned long long dstart = (kDbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
+        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
             const bool next_new_tile = (fk + 1 == nb);
-            const int64_t nt = next_new_tile ? tile + stride : tile;
+            const int64_t nt = next_new_tile ? (kTicket ? next_ticket_tile() : tile + stride) : tile;
             const int nk = next_new_tile ? 0 : fk + 1;
+#ifdef FE_EXPERIMENTS
+            const unsigned long long c0 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
+#endif
             wait_vmcnt<0>();
+#ifdef FE_EXPERIMENTS
+            const unsigned long long c1 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
+#endif
             double jk[ND * ND], bf[G::KSJ];
 #pragma unroll
             for (int k = 0; k < ND * ND; ++k) jk[k] = L->j[k * G::TEL + n];
@@ -353,6 +387,18 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) accs[r][q] = 0.0;
             }
+            if (kDbg & 1) {     // experiment: no MFMAs (the B values stay live)
+                double sum = 0.0;
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq) sum += bf[jq];
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t) acc[r][t] = v4d{sum, sum, sum, a_big(t, 0, r)};
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q) accs[r][q] = sum;
+                }
+            } else {
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq)
 #pragma unroll
@@ -365,7 +411,12 @@ __device__ __forceinline__ void div3d_mfma_body(
                         accs[r][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * NC + r) * G::NS + q) * 16], bf[jq],
                                                                         accs[r][q], 0, 0, 0);
                 }
+            }
             double* ob = L->u[0];   // every B value is in a register by now (the MFMAs consumed them)
+            bool requested = false;
+#ifdef FE_EXPERIMENTS
+            const unsigned long long c2 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
+#endif
 #pragma unroll
             for (int x = 0; x < ND; ++x) {
                 double* plane = nullptr;
@@ -400,18 +451,33 @@ __device__ __forceinline__ void div3d_mfma_body(
                                   ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc)) : v2d{0.0, 0.0};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // plane x has left the buffer
+                if (kEarly && x == ND - 1 && nt < tEnd && !(kDbg & 8)) { issue_loads(nt, nk, next_new_tile); requested = true; }
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
-                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
-                        __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
+                        if (kDbg & 2) { if (held[c][0] == 1.2345e-300) op[2 * qc] = held[c][1]; }   // experiment: no stores
+                        else __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+                    }
                 }
                 wave_lds_fence();
             }
-            if (nt < tEnd) issue_loads(nt, nk, next_new_tile);
+            if (!requested && nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);   // (MODE 5: last plane not asked for)
+#ifdef FE_EXPERIMENTS
+            const unsigned long long c3 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
+            dw += c1 - c0; dm += c2 - c1; de += c3 - c2; ++dn;
+#endif
             fk = nk;
             tile = nt;
         }
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) {
+            unsigned long long* d = fe_dbg_w8[bid * G::WAVES + wave];
+            d[0] = dw; d[1] = dm; d[2] = de; d[3] = dn;
+            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            d[5] = dstart; d[6] = __builtin_amdgcn_s_memrealtime(); d[7] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        }
+#endif
         return;
     }
     bool first = true;

@@ -127,7 +127,7 @@ unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
 
 // grad of tetrahedra p = 5 (Np = 56): grad by components with the A fragments in LDS, one block per CU
 int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
-                   hipStream_t s, bool* launched) {
+                   hipStream_t s, bool* launched, int dbg = 0) {
     using G = fe::DivGeom<56, 1, 4, 3, true, true>;   // eight waves per block, one block per CU
     const int64_t nTiles = E / G::TEL;
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
@@ -140,6 +140,27 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
     });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
+#ifdef FE_EXPERIMENTS
+#define FE_P5_CASE(DBG)                                                                                                   \
+    case DBG: {                                                                                                           \
+        static PerDeviceOnce once_dbg;                                                                                    \
+        once_dbg.run([] {                                                                                                 \
+            return configure_kernel(fe::div3d_mfma_kernel<56, 1, DBG, 4, 3, true, true>, "experiment", G::LDS_BYTES,      \
+                                    G::THREADS, G::BLOCKS_PER_CU);                                                        \
+        });                                                                                                               \
+        hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, DBG, 4, 3, true, true>),                                         \
+                           dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(G::THREADS), G::LDS_BYTES, s, J, D,        \
+                           nullptr, P, nb, E, nTiles, opT, 0);                                                            \
+        return FE_OK;                                                                                                     \
+    }
+    switch (dbg) {
+        FE_P5_CASE(1) FE_P5_CASE(2) FE_P5_CASE(3) FE_P5_CASE(8) FE_P5_CASE(9) FE_P5_CASE(10) FE_P5_CASE(11) FE_P5_CASE(32) FE_P5_CASE(16) FE_P5_CASE(64) FE_P5_CASE(80)
+        default: break;
+    }
+#undef FE_P5_CASE
+#else
+    (void)dbg;
+#endif
     hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
                        dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
     return FE_OK;
@@ -486,7 +507,11 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
     if (path == kPathTiled) return launch_tiled(ta, s);
     if (path == kPathMfma && Np == 56) {   // p = 5: too many A fragments for the row-permuted kernel
         bool launched = false;
-        if (int rc = launch_grad_p5(Jfull, D, Pt, nb, E, opT, s, &launched)) return rc;
+        int dbg5 = 0;
+#ifdef FE_EXPERIMENTS
+        if (variant >= 1000) dbg5 = (variant - 1000) & 127;   // experiment flags, see fe_div.h
+#endif
+        if (int rc = launch_grad_p5(Jfull, D, Pt, nb, E, opT, s, &launched, dbg5)) return rc;
         if (launched) {
             FE_HIP_CHECK(hipGetLastError());
             return FE_OK;
@@ -1478,6 +1503,11 @@ int fe_einsum_generic(const fe_einsum_desc* d, const void* const* operands, void
 int fe_dbg_read_clock(unsigned long long* out2) {
     FE_HIP_CHECK(hipDeviceSynchronize());
     FE_HIP_CHECK(hipMemcpyFromSymbol(out2, HIP_SYMBOL(fe::fe_dbg_clock), 16));
+    return FE_OK;
+}
+int fe_dbg_read_w8(unsigned long long* out, int n_waves) {
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_w8), (size_t)n_waves * 64));
     return FE_OK;
 }
 int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
