@@ -590,6 +590,13 @@ def main() -> None:
             line["roofline"]["traffic_source"] = {k: rec.get(k) for k in ("kernel", "source_sha", "profile", "E")}
             line["mfma_util"] = rec.get("mfma_util")
             line["mfma_util_source"] = rec.get("mfma_util_formula")
+            # the PMC passes run with one allocation per array (their launch time is the placement lottery of
+            # DESIGN section 3d); the busy cycles per launch are fixed, so the same ratio at THIS run's launch time:
+            busy = ((rec.get("counters") or {}).get("SQ_VALU_MFMA_BUSY_CYCLES") or {}).get("mean")
+            sclk = (((extra.get("device_under_load") or {}).get("freq_sclk_mhz")) or {}).get("mean")
+            if busy and sclk:
+                line["mfma_busy_cycles_per_launch"] = busy
+                line["mfma_util_at_this_launch_time"] = round(busy / (1024 * (kernel_s / args.steps) * sclk * 1e6), 4)
         else:
             line["roofline"]["traffic_note"] = note or "the committed PMC profile is of the default (fused, unprepared) launch"
             line["mfma_util"] = None
