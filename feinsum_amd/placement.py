@@ -184,5 +184,8 @@ def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
               "best_base_mib": best // MIB, "best_ms": round(fine[best], 5),
               "scan_positions": len(coarse), "scan_median_ms": round(ordered[len(ordered) // 2], 5),
               "scan_min_ms": round(ordered[0], 5), "scan_max_ms": round(ordered[-1], 5),
-              "fast_positions_mib": [b // MIB for b, t in coarse.items() if t < 0.97 * ordered[len(ordered) // 2]]}
+              "fast_positions_mib": [b // MIB for b, t in coarse.items() if t < 0.97 * ordered[len(ordered) // 2]],
+              # False: no position stood out (an arena of one class of physical memory, or a launch that writes a
+              # single stream): the layout then simply sits where it timed best
+              "class_boundary_found": bool(fine[best] < 0.97 * ordered[len(ordered) // 2])}
     return arena, views, report
