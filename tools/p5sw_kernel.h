@@ -1,6 +1,8 @@
 // p5sw_kernel.h -- EXPERIMENT (not part of the library; driver: tools/p5sw.hip).  Measured on MI355X at E = 1e6:
-// 0.414 ms in its first form, 0.46-0.50 ms with the side work pinned under the MFMAs (512 registers and spills),
-// against 0.376-0.386 ms for the shipped eight-wave kernel -- rejected, kept for the record (p = 5).
+// 0.414 ms in its first form (the compiler hoists the J-combine out from under the MFMAs), 0.46-0.50 ms with the side
+// work pinned by scheduling barriers and the next tile's fragments prefetched (512 registers and spills), 0.433 ms in
+// this leaner pinned form (434 registers, no spills) -- against 0.376-0.386 ms for the shipped eight-wave kernel:
+// rejected, kept for the record (p = 5).
 //
 // grad of tetrahedra p = 5 (Np = 56), 'xre,rij,ej->xei', ONE wave per SIMD with the operator's
 // big-tile MFMA fragments resident in registers and everything else of a tile in the shadow of its MFMAs.
@@ -122,57 +124,60 @@ __global__ __launch_bounds__(256, 1) void grad_p5_kernel(const double* __restric
     int64_t tile = (int64_t)blockIdx.x * G::WAVES + wave;
     if (tile >= nTiles) return;
     int64_t prev = -1;
-    int jbuf = 0;
-    double bf[G::KSJ], jk[9];
-    auto read_fragments = [&](double (&b)[G::KSJ], double (&jj)[9], int buf) {
-        const double* jt = L->j[buf];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) jj[k] = jt[k * G::TEL + n];
-#pragma unroll
-        for (int jq = 0; jq < G::KSJ; ++jq) b[jq] = L->u[tile_index<NP>(n, 4 * jq + g)];
-    };
+    int jbuf = 0, iteration = 0;
     issue_loads(tile, 0);
-    wait_vmcnt<0>();
-    read_fragments(bf, jk, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (tile + stride < nTiles) issue_loads(tile + stride, 1);
-
-    // one (plane, value) unit of the J-combine of an accumulator set: out[x][e0 + n][i0 + g + 4 q]
-    auto combine_unit = [&](const v4d (&acc)[3], int t, int unit) {
-        const int x = unit >> 2, q = unit & 3;
-        const double v = jk[x * 3] * acc[0][q] + jk[x * 3 + 1] * acc[1][q] + jk[x * 3 + 2] * acc[2][q];
-        L->o[x][tile_index<NP>(n, 16 * t + g + 4 * q)] = v;
-    };
 
     while (true) {
-        const int64_t nt = tile + stride, nnt = nt + stride;
-        v4d acc[G::BT][3];   // [row tile][r]: separate registers per row tile, so that the combine of one runs under the next
+        const int64_t nt = tile + stride;
+        // issue order: L(t) [iteration t-1, after its fragment reads] S(t-2) [iteration t-1] | wait L(t)
+        if (iteration >= 2) wait_vmcnt<G::STORES>();
+        else wait_vmcnt<0>();
+        ++iteration;
+        double bf[G::KSJ], jk[9];
+        {
+            const double* jt = L->j[jbuf];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) jk[k] = jt[k * G::TEL + n];
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq) bf[jq] = L->u[tile_index<NP>(n, 4 * jq + g)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int jq = 0; jq < G::KSJ; ++jq) asm volatile("" : "+v"(bf[jq]));
+        if (nt < nTiles) issue_loads(nt, jbuf ^ 1);
+
+        // one (plane, value) unit of the J-combine of an accumulator set: out[x][e0 + n][16 t + g + 4 q]
+        auto combine_unit = [&](const v4d (&acc)[3], int t, int unit) {
+            const int x = unit >> 2, q = unit & 3;
+            const double v = jk[x * 3] * acc[0][q] + jk[x * 3 + 1] * acc[1][q] + jk[x * 3 + 2] * acc[2][q];
+            L->o[x][tile_index<NP>(n, 16 * t + g + 4 * q)] = v;
+        };
+
+        v4d acc[2][3];   // ping-pong: the combine of one row tile runs under the MFMAs of the next
 #pragma unroll
         for (int t = 0; t < G::BT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) acc[t][r] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < 3; ++r) acc[t & 1][r] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
-                    acc[t][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bf[jq], acc[t][r], 0, 0, 0);
+                    acc[t & 1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(abig[t][jq][r], bf[jq], acc[t & 1][r], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // side work in the shadow of the MFMAs
                 if (t == 0) {
                     if (prev >= 0 && jq % 4 == 1 && jq / 4 < 3) drain_read(jq / 4);
                     if (prev >= 0 && jq % 4 == 3 && jq / 4 < 3) drain_store(jq / 4, prev);
                 } else if (jq >= 1 && jq <= 12) {
-                    combine_unit(acc[t - 1], t - 1, jq - 1);
+                    combine_unit(acc[(t - 1) & 1], t - 1, jq - 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        double accs[G::NS][3], bfn[G::KSJ], jkn[9];
+        double accs[G::NS][3];
 #pragma unroll
         for (int q = 0; q < G::NS; ++q)
 #pragma unroll
             for (int r = 0; r < 3; ++r) accs[q][r] = 0.0;
-        // the A values of the 4-row groups come from the LDS table one k-step ahead of their MFMAs
         double as_c[3][G::NS], as_n[3][G::NS];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -192,18 +197,7 @@ __global__ __launch_bounds__(256, 1) void grad_p5_kernel(const double* __restric
                 for (int q = 0; q < G::NS; ++q)
                     accs[q][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_c[r][q], bf[jq], accs[q][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (jq >= 1 && jq <= 12) combine_unit(acc[G::BT - 1], G::BT - 1, jq - 1);
-            if (jq == 6 && nt < nTiles) {
-                // the next tile has landed (requested a whole iteration ago): its fragments go to registers now, so
-                // that the tile buffer is free for the tile after it.  Issue order: L(t+1) S(t-1) | wait L(t+1)
-                if (prev >= 0) wait_vmcnt<G::STORES>();
-                else wait_vmcnt<0>();
-                read_fragments(bfn, jkn, jbuf ^ 1);
-            }
-            if (jq == 12 && nt < nTiles) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (nnt < nTiles) issue_loads(nnt, jbuf);
-            }
+            if (jq >= 1 && jq <= 12) combine_unit(acc[(G::BT - 1) & 1], G::BT - 1, jq - 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -222,10 +216,6 @@ __global__ __launch_bounds__(256, 1) void grad_p5_kernel(const double* __restric
         if (nt >= nTiles) break;
         tile = nt;
         jbuf ^= 1;
-#pragma unroll
-        for (int jq = 0; jq < G::KSJ; ++jq) bf[jq] = bfn[jq];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) jk[k] = jkn[k];
     }
 #pragma unroll
     for (int x = 0; x < 3; ++x) { drain_read(x); drain_store(x, prev); }
