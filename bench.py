@@ -478,8 +478,9 @@ def main() -> None:
                 out_dicts.append({name: views[f"{k}>{name}"] for name in expr.output_names})
             return stages, out_dicts
 
-        arena, views, placement_report = placement.tune_base(
-            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill,
+        # (a launch with a single write stream -- div alone -- has no class boundary to look for: one arena)
+        arena, views, placement_report = placement.tune_base_retry(
+            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill, attempts=1 if args.workload == "div" else 3,
             arena_gib=args.arena_gib / max(1, info.world_size if os.environ.get("FEINSUM_DIST_BACKEND") == "gloo" else 1))
         stages, out_dicts = stages_of(views)
     else:

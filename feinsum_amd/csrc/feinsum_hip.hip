@@ -551,6 +551,10 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
     return FE_OK;
 }
 
+// body order of the fused launches (fe_fused.h): chosen by measurement (tools/fused_order_ab.py)
+constexpr int kFusedOrderGradDiv = 1;   // the younger half of the grid runs grad first: -1.5 ... -3.7 % in every placement
+constexpr int kFusedOrderWaveOp = 3;    // the younger half runs grad, div, lift (rotating all three bodies by thirds of the grid cost time)
+
 // div then grad in one persistent launch (full tiles only; e_done_* report what was covered)
 template <int NP, int MG, int MD>
 int launch_graddiv(const double* J, const double* D, const void* prep, const fe::GradFields& Pg,
@@ -573,12 +577,16 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
     const unsigned grid = persistent_grid(nTiles, 4);
+    int op_arg = kFusedOrderGradDiv << 8;   // see fe_fused.h
+#ifdef FE_EXPERIMENTS
+    if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
+#endif
     if (prep)
         hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD, true>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, prep,
-                           Pg, Pd, E, nTilesG, nTilesD, 0);
+                           Pg, Pd, E, nTilesG, nTilesD, op_arg);
     else
         hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr,
-                           Pg, Pd, E, nTilesG, nTilesD, 0);
+                           Pg, Pd, E, nTilesG, nTilesD, op_arg);
     return FE_OK;
 }
 
@@ -615,6 +623,10 @@ int launch_waveop(fe::WaveOpArgs a, const fe::GradFields& Pg, const fe::FieldPtr
     a.nTilesG = a.E / (16 * MG);
     a.nTilesD = a.E / (16 * MD);
     a.nTilesF = a.E / (16 * MF);
+    a.order = kFusedOrderWaveOp;
+#ifdef FE_EXPERIMENTS
+    if (const char* o = getenv("FE_FUSED_ORDER")) a.order = atoi(o);
+#endif
     *launched = a.nTilesG > 0 || a.nTilesD > 0 || a.nTilesF > 0;   // remainders included
     if (!*launched) return FE_OK;
     switch (nb) {

@@ -580,7 +580,7 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
             return lambda n: b.time_batch(n, q.stream_ptr)
 
         with torch.cuda.device(q.torch_device):
-            arena, views, _report = placement.tune_base(arrays, q.torch_device, make_step, fill=fill)
+            arena, views, _report = placement.tune_base_retry(arrays, q.torch_device, make_step, fill=fill, attempts=2)
         arg_dict, out_dict = {n: views[n] for n in names}, {n: views[n] for n in out_dict}
         del staged
     _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=prepare)

@@ -73,3 +73,11 @@ def test_tuned_layout_gives_the_same_results():
     make_step(views)(1)
     q.finish()
     assert torch.equal(views["_fe_out"], ref)
+
+    # again in fresh arenas while no class boundary shows (a 1 GiB arena has none, as a rule): the fastest is kept
+    arena, views, report = placement.tune_base_retry(arrays, "cuda", make_step, attempts=2, arena_gib=1.0, gap_mib=2,
+                                                     fill=fill, coarse_launches=2, launches=2, rounds=1)
+    assert report["arenas_tried"] in (1, 2) and isinstance(report["class_boundary_found"], bool)
+    make_step(views)(1)
+    q.finish()
+    assert torch.equal(views["_fe_out"], ref)
