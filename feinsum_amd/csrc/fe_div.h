@@ -191,8 +191,13 @@ __device__ __forceinline__ void div3d_mfma_body(
     // nb fields share J and D ('xre,rij,xej->ei' x nb: tuning/impls/batched_xre_rij_xej_to_ei.py):
     // the wave walks (tile, field) units, field fastest; J is loaded with the first field of a
     // tile and stays in LDS until the last field's B fragments are built.
+    // experiment (kDbg & 4): the walk covers the two halves of the element range at the same time (even steps in the
+    // first half, odd steps in the second), so that the ONE output stream of div has two write windows -- which a class
+    // boundary in the middle of the output array can then split
+    const int64_t half_tiles = (nTiles + 1) / 2;
+    auto phys = [&](int64_t t) -> int64_t { return (kDbg & 4) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
     auto issue_loads = [&](int64_t tile, int fk, bool with_j) {
-        const int64_t e0 = tile * G::TEL;
+        const int64_t e0 = phys(tile) * G::TEL;
         const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);
 #pragma unroll
         for (int x = 0; x < G::NPLANES; ++x) {
@@ -511,7 +516,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     int iteration = 0, fk = 0;
     while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
-        const int64_t e0 = tile * G::TEL;
+        const int64_t e0 = phys(tile) * G::TEL;
         double* const out = field_out(P, fk);
         const bool next_new_tile = (fk + 1 == nb);
         const int64_t nt = next_new_tile ? tile + stride : tile;

@@ -221,20 +221,23 @@ __device__ __forceinline__ void grad3d_mfma_body(
     int64_t tile = (int64_t)bid * G::WAVES + wave;
 
     double afrag[G::RT][G::KS];
+    // experiment (kDbg & 128): the walk covers both halves of the element range at once (see fe_div.h, kDbg & 4)
+    const int64_t half_tiles = (nTiles + 1) / 2;
+    auto phys = [&](int64_t t) -> int64_t { return (kDbg & 128) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
     bool pre = false;   // unit 1 already requested
     // the loads of this wave's first two units (behind the operator copy / the fragment loads)
     auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
         if (!(tile < tEnd) || (kDbg & 8)) return 0;
-        grad_issue_u<NP, M, kNT>(P.u[0], tile, lane, lds_addr_uniform(L->u[0]));
-        grad_issue_j<NP, M, kPlain>(P, E, tile, lane, lds_addr_uniform(L->j[0]));
+        grad_issue_u<NP, M, kNT>(P.u[0], phys(tile), lane, lds_addr_uniform(L->u[0]));
+        grad_issue_j<NP, M, kPlain>(P, E, phys(tile), lane, lds_addr_uniform(L->j[0]));
         if (nb > 1) {
-            grad_issue_u<NP, M, kNT>(P.u[1], tile, lane, lds_addr_uniform(L->u[1]));
+            grad_issue_u<NP, M, kNT>(P.u[1], phys(tile), lane, lds_addr_uniform(L->u[1]));
             pre = true;
             return 1;
         }
         if (tile + stride < tEnd) {
-            grad_issue_u<NP, M, kNT>(P.u[0], tile + stride, lane, lds_addr_uniform(L->u[1]));
-            grad_issue_j<NP, M, kPlain>(P, E, tile + stride, lane, lds_addr_uniform(L->j[1]));
+            grad_issue_u<NP, M, kNT>(P.u[0], phys(tile + stride), lane, lds_addr_uniform(L->u[1]));
+            grad_issue_j<NP, M, kPlain>(P, E, phys(tile + stride), lane, lds_addr_uniform(L->j[1]));
             pre = true;
             return 2;
         }
@@ -316,9 +319,9 @@ __device__ __forceinline__ void grad3d_mfma_body(
         if (kDbg & 8) {
             wait_vmcnt<0>();
         } else if (nt < tEnd) {
-            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), nt, lane, lds_addr_uniform(L->u[ub ^ 1]));
+            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]));
             if (next_new_tile) {
-                if (!pre) grad_issue_j<NP, M, kPlain>(P, E, nt, lane, lds_addr_uniform(L->j[jbuf ^ 1]));
+                if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
                 if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
                 else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
             } else {
@@ -339,7 +342,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
         out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
         out_x[2] = kPlain ? out_x[0] + 2 * E * NP : grad_plane_out(P, fk, 2);
         int obuf = 0;
-        const int64_t e0 = tile * G::TEL;
+        const int64_t e0 = phys(tile) * G::TEL;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             // ---- stage 1 on sub-tile m

@@ -283,6 +283,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 128>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
@@ -310,6 +311,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             break;
         case 64: FE_GRAD_CASE(64); break;
         case 96: FE_GRAD_CASE(96); break;
+        case 128: FE_GRAD_CASE(128); break;
 #endif
         default:
             if (gsec)
@@ -344,6 +346,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 4>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
         return rc;
@@ -358,6 +361,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 2: FE_DIV_CASE(2); break;
         case 3: FE_DIV_CASE(3); break;
         case 8: FE_DIV_CASE(8); break;
+        case 4: FE_DIV_CASE(4); break;
 #endif
         default:
             if (prep)
@@ -522,7 +526,7 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
     if (path == kPathMfma) {
         int dbg = 0;
 #ifdef FE_EXPERIMENTS
-        if (variant >= 1000) dbg = (variant - 1000) & 127;   // experiment flags, see fe_grad.h
+        if (variant >= 1000) dbg = (variant - 1000) & 255;   // experiment flags, see fe_grad.h
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
