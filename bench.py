@@ -421,8 +421,12 @@ def main() -> None:
     if len(exprs) > 1:                   # J and D counted once
         bytes_step -= 8.0 * (9 * E + 3 * NP * NP)
 
-    def bind(stages, out_dicts):
-        return operator.bind_operator(stages, q, out_dicts=out_dicts, transform=args.variant, fuse=not args.no_fuse,
+    # div alone in the tuned placement: its one output array gets two write windows (FE_VARIANT_MFMA_SPLIT), which the
+    # class boundary the placement puts into the middle of that array then splits
+    variant = "mfma_split" if (args.variant == "auto" and args.workload == "div" and args.placement == "tuned") else args.variant
+
+    def bind(stages, out_dicts, variant_=None):
+        return operator.bind_operator(stages, q, out_dicts=out_dicts, transform=variant_ or variant, fuse=not args.no_fuse,
                                       prepare=args.prepare)
 
     def separate_allocations():
@@ -478,9 +482,9 @@ def main() -> None:
                 out_dicts.append({name: views[f"{k}>{name}"] for name in expr.output_names})
             return stages, out_dicts
 
-        # (a launch with a single write stream -- div alone -- has no class boundary to look for: one arena)
         arena, views, placement_report = placement.tune_base_retry(
-            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill, attempts=1 if args.workload == "div" else 3,
+            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill, attempts=3,
+            **({"stride_mib": 64, "fine_step_mib": 16, "coarse_launches": 6} if variant == "mfma_split" else {}),
             arena_gib=args.arena_gib / max(1, info.world_size if os.environ.get("FEINSUM_DIST_BACKEND") == "gloo" else 1))
         stages, out_dicts = stages_of(views)
     else:
@@ -525,7 +529,7 @@ def main() -> None:
     # A/B outside the timed region: the same launch on one-torch-allocation-per-array operands
     separate_ms = None
     if args.placement == "tuned" and not args.no_protocol:
-        op_sep = bind(*separate_allocations())
+        op_sep = bind(*separate_allocations(), variant_=args.variant)     # (the plain walk: what a caller gets by default)
         sb = step_batch_of(op_sep)
         sb(max(args.warmup, 10))
         separate_ms = sb(args.steps) / args.steps * 1e3
@@ -583,7 +587,7 @@ def main() -> None:
                             setup_launches=args.setup_launches,
                             wall_s=wall_s, kernel_s=kernel_s, flops_step_all=flops_all, flops_step_rank0=flops_step,
                             bytes_step_rank0=bytes_step, elems_rank0=E, elems_total=args.elems_total,
-                            variant=args.variant, device_name=q.device.name, entry_points=op.entry_points,
+                            variant=variant, device_name=q.device.name, entry_points=op.entry_points,
                             extra=extra)
         rec, note = committed_counters(args.workload, E)
         if rec is not None and not args.no_fuse and not args.prepare:      # (the profiled kernels are the default ones)

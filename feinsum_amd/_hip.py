@@ -18,8 +18,11 @@ from typing import Optional, Sequence
 from feinsum_amd.diagnostics import HipLibraryError, InvalidParameterError
 
 FE_OK, FE_EINVAL, FE_EUNSUPPORTED, FE_EHIP = 0, -1, -2, -3
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_TILED = 0, 1, 2, 3
-VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MFMA, "tiled": VARIANT_TILED}
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_TILED, VARIANT_MFMA_SPLIT = 0, 1, 2, 3, 4
+# "mfma_split": div of tetrahedra p = 1..4 only -- the MFMA kernel walking both halves of the element range at once
+# (two write windows for its one output: include/feinsum_hip.h, FE_VARIANT_MFMA_SPLIT)
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "mfma": VARIANT_MFMA, "tiled": VARIANT_TILED,
+            "mfma_split": VARIANT_MFMA_SPLIT}
 
 #: every symbol declared in include/feinsum_hip.h (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = (

@@ -59,6 +59,8 @@ __device__ unsigned long long fe_dbg_w8[4096][8];
 // transposition buffer are the same LDS (the next tile is requested after the stores), which is
 // what lets two waves per SIMD fit beside 75 KB of fragments -- the partner wave's MFMAs cover
 // the exposed load.
+constexpr int kDivWalkSplit = 2;   // op_flags bit of div3d_mfma_body
+
 template <int NP, int M, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false>
 struct DivGeom {
     static constexpr int TEL = 16 * M;
@@ -111,9 +113,12 @@ struct DivGeom {
 template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, const FieldPtrs& P,
-    int nb, int64_t E, int64_t nTiles, int opT, int jes, const unsigned bid, const unsigned nblk,
+    int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
     const GradFields* __restrict__ Q = nullptr) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
+    // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
+    // only) = the walk covers both halves of the element range at once, see `phys` below
+    const int opT = op_flags & 1;
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,11 +196,13 @@ __device__ __forceinline__ void div3d_mfma_body(
     // nb fields share J and D ('xre,rij,xej->ei' x nb: tuning/impls/batched_xre_rij_xej_to_ei.py):
     // the wave walks (tile, field) units, field fastest; J is loaded with the first field of a
     // tile and stays in LDS until the last field's B fragments are built.
-    // experiment (kDbg & 4): the walk covers the two halves of the element range at the same time (even steps in the
-    // first half, odd steps in the second), so that the ONE output stream of div has two write windows -- which a class
-    // boundary in the middle of the output array can then split
+    // FE_VARIANT_MFMA_SPLIT: the walk covers the two halves of the element range at the same time (even steps in the
+    // first half, odd steps in the second), so that the ONE output stream of div has two write windows -- which a
+    // boundary between the two classes of physical memory in the middle of the output array then splits (DESIGN.md
+    // section 3d: 0.1914 against 0.1993 ms at E = 1e6; 1.3 % slower than the plain walk anywhere else)
     const int64_t half_tiles = (nTiles + 1) / 2;
-    auto phys = [&](int64_t t) -> int64_t { return (kDbg & 4) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
+    const bool split_walk = (op_flags & kDivWalkSplit) != 0;
+    auto phys = [&](int64_t t) -> int64_t { return split_walk ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
     auto issue_loads = [&](int64_t tile, int fk, bool with_j) {
         const int64_t e0 = phys(tile) * G::TEL;
         const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);

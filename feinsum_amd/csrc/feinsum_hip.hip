@@ -346,7 +346,6 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
-            configure_kernel(fe::div3d_mfma_kernel<NP, M, 4>, "experiment", G::LDS_BYTES, 256, 1);
         }
 #endif
         return rc;
@@ -361,7 +360,6 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 2: FE_DIV_CASE(2); break;
         case 3: FE_DIV_CASE(3); break;
         case 8: FE_DIV_CASE(8); break;
-        case 4: FE_DIV_CASE(4); break;
 #endif
         default:
             if (prep)
@@ -992,17 +990,21 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
     if (op_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "div: bad operator flags %d", op_flags);
     const int opT = (op_flags & FE_OP_TRANSPOSED) ? 1 : 0;
 #ifdef FE_EXPERIMENTS
-    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_TILED && variant < 1000))
+    if (variant < FE_VARIANT_AUTO || (variant > FE_VARIANT_MFMA_SPLIT && variant < 1000))
 #else
-    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_TILED)
+    if (variant < FE_VARIANT_AUTO || variant > FE_VARIANT_MFMA_SPLIT)
 #endif
         return fail(FE_EUNSUPPORTED, "div: unknown variant %d", variant);
     if (E == 0) return FE_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool mfma_ok = Np == 56 || Np == 35 || Np == 20 || Np == 10 || Np == 4;
+    const bool split_walk = variant == FE_VARIANT_MFMA_SPLIT;
+    if (split_walk && !(Np == 35 || Np == 20 || Np == 10 || Np == 4))
+        return fail(FE_EUNSUPPORTED, "div: the split walk is a flavour of the p = 1..4 MFMA kernels (Np=%d)", Np);
     const fe::TiledArgs ta = tiled_args(FE_FAMILY_DIV, J, D, P, b, E, 3, Np, 0, 0, opT, 0, 0);
     KernelPath path;
-    if (int rc = choose_path(variant >= 1000 ? FE_VARIANT_MFMA : variant, mfma_ok, tiled_fits(ta), "div", Np, &path))
+    if (int rc = choose_path((variant >= 1000 || split_walk) ? FE_VARIANT_MFMA : variant, mfma_ok, tiled_fits(ta), "div", Np,
+                             &path))
         return rc;
     if (path == kPathTiled) return launch_tiled(ta, s);
     if (path == kPathMfma && Np == 56) {   // p = 5
@@ -1018,11 +1020,12 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
     if (path == kPathMfma) {
         const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
         int rc = FE_OK;
+        const int opf = opT | (split_walk ? fe::kDivWalkSplit : 0);
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
-            case 20: rc = launch_div<20, 1>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
-            case 10: rc = launch_div<10, 3>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
-            default: rc = launch_div<4, 5>(J, D, prep, P, b, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
+            case 20: rc = launch_div<20, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
+            case 10: rc = launch_div<10, 3>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
+            default: rc = launch_div<4, 5>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
         }
         if (rc != FE_OK) return rc;
     }

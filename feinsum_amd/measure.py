@@ -273,7 +273,7 @@ class _FamilyLaunch:
         operator array in place.  Returns the number of prepared groups."""
         import torch
 
-        if self.variant not in (_hip.VARIANT_AUTO, _hip.VARIANT_MFMA) or self.group_family == FAMILY_GRADPLANES \
+        if self.variant not in (_hip.VARIANT_AUTO, _hip.VARIANT_MFMA, _hip.VARIANT_MFMA_SPLIT) or self.group_family == FAMILY_GRADPLANES \
                 or self.plan.family not in (FAMILY_GRAD, FAMILY_DIV, FAMILY_FACEMASS):
             return 0
         done = 0

@@ -129,7 +129,8 @@ def split_order(stages: Sequence[Sequence[Tuple[str, Tuple[int, ...], Any]]]) ->
 def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
               make_step: Callable[[Dict[str, Any]], Callable[[int], float]], *,
               arena_gib: float = 66.0, gap_mib: int = 64, fill: Callable[[str, Any], None] | None = None,
-              coarse_launches: int = 10, launches: int = 20, rounds: int = 3):
+              coarse_launches: int = 10, launches: int = 20, rounds: int = 3, stride_mib: int | None = None,
+              fine_step_mib: int | None = None):
     """
     Pick the POSITION of the layout inside one large arena that makes the launch fastest.
 
@@ -166,11 +167,17 @@ def tune_base(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: Any,
     # the launch is fast while the class boundary cuts through the written arrays (the plateau is as wide as one array /
     # one plane, with linear ramps of the same width either side): coarse steps of a quarter of the layout, at least
     # 256 MiB and at most 1 GiB, then the neighbourhood of the best position in steps of at most 128 MiB
+    # (*stride_mib* / *fine_step_mib* override: a launch with ONE written array that walks it in two windows -- div,
+    # FE_VARIANT_MFMA_SPLIT -- is fast only while the boundary lies near the middle of that array: a narrow peak)
     stride = min(max(length // 4 // ALIGN * ALIGN, 256 * MIB), 1024 * MIB)
+    if stride_mib is not None:
+        stride = max(ALIGN, stride_mib * MIB // ALIGN * ALIGN)
     coarse = {b: time_at(b, coarse_launches, 1) for b in range(0, last + 1, stride)}
     best = min(coarse, key=coarse.get)
     fine = {best: time_at(best, launches, rounds)}
     step = max(64 * MIB, min(stride // 4, 128 * MIB)) // ALIGN * ALIGN
+    if fine_step_mib is not None:
+        step = max(ALIGN, fine_step_mib * MIB // ALIGN * ALIGN)
     for k in range(-(stride // step), stride // step + 1):
         b = (best + k * step) // ALIGN * ALIGN
         if 0 <= b <= last and b not in fine:

@@ -54,6 +54,12 @@ extern "C" {
 #define FE_VARIANT_GENERIC 1
 #define FE_VARIANT_MFMA    2
 #define FE_VARIANT_TILED   3  /* LDS-tiled VALU kernel, any shape whose operator fits in LDS */
+#define FE_VARIANT_MFMA_SPLIT 4 /* div of tetrahedra p = 1..4 only (fe_div3d_f64 and its _ex / _batched / _prepared forms):
+                                 * the MFMA kernel walking both halves of the element range at once, so that the one
+                                 * output array has two write windows.  Faster (4 % at E = 1e6) when the output lies
+                                 * across a boundary between the two classes of physical memory (feinsum_amd/placement.py),
+                                 * 1 % slower otherwise; results are those of FE_VARIANT_MFMA to the last bit or two.  Other entry points
+                                 * answer FE_EUNSUPPORTED. */
 
 /* families, for fe_time_launches / fe_flops_per_element */
 #define FE_FAMILY_GRAD     1

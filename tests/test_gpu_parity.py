@@ -656,3 +656,32 @@ def test_config5_eight_million_elements(torch_cuda):
     for a, b in zip(fused, plain):
         for k in a:
             assert torch.equal(a[k], b[k]) and bool(torch.isfinite(a[k]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Np", [4, 10, 20, 35])
+@pytest.mark.parametrize("E", [16, 17, 79, 1000, 32784, 70003])
+def test_div_split_walk_matches_the_mfma_kernel(torch_cuda, Np, E):
+    """FE_VARIANT_MFMA_SPLIT ("mfma_split"): div walking both halves of the element range at once -- the same tiles, the
+    same arithmetic, another order (odd and even tile counts, a remainder behind the last tile, several tiles per wave
+    at E = 70 003), single and batched.  Equal to the plain walk to the last bit or two: the compiler contracts the
+    first tile of a wave differently from its later ones, and which tile comes first differs between the walks."""
+    torch = torch_cuda
+    for expr in (dg.div(Np), dg.batched_div(3, Np)):
+        dev = _device_inputs(torch, expr, E, seed=E + Np)
+        plain = f.evaluate(expr, 0, dev, transform="mfma", wait=True)
+        split = f.evaluate(expr, 0, dev, transform="mfma_split", wait=True)
+        generic = f.evaluate(expr, 0, dev, transform="generic", wait=True)
+        assert set(plain) == set(split)
+        for name in plain:
+            assert torch.allclose(plain[name], split[name], rtol=1e-14, atol=0.0), (name, Np, E)
+            assert torch.allclose(generic[name], split[name], rtol=1e-12, atol=0.0), (name, Np, E)
+
+
+@pytest.mark.gpu
+def test_split_walk_is_a_div_variant_only(torch_cuda):
+    torch = torch_cuda
+    for expr in (dg.grad(35), dg.face_mass(4), dg.div(56)):
+        dev = _device_inputs(torch, expr, 100, seed=1)
+        with pytest.raises(NotImplementedError):
+            f.evaluate(expr, 0, dev, transform="mfma_split", wait=True)
