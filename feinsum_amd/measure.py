@@ -24,8 +24,11 @@ Argument conventions kept from the reference:
                (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
                a variant explicitly; in a dict, ``"prepared": True`` lets a
                bound launch (``timeit``) use a prepared copy of its operator
-               matrices and ``"placement": "tuned"`` makes ``timeit`` place the
-               arrays where the launch runs fastest (``feinsum_amd.placement``).
+               matrices; ``"placement"``: ``"tuned"`` makes ``timeit`` place the
+               arrays where the launch runs fastest (``feinsum_amd.placement``),
+               ``"separate"`` keeps one allocation per array, the default
+               ``"auto"`` (or ``$FEINSUM_PLACEMENT``) tunes when the launch
+               writes several streams of >= 128 MiB each.
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -534,6 +537,34 @@ def validate_batched_einsum_transform(einsum: BatchedEinsum, cq: Any, transform:
     logger.info("Statistically verified the soundness of the transformation")
 
 
+#: a written array (or plane of one) of at least this size makes ``timeit`` place the arrays itself by default
+AUTO_PLACEMENT_MIN_PLANE_BYTES = 128 << 20
+
+
+def _wants_tuned_placement(transform: Any, out_dict: Mapping[str, Any]) -> bool:
+    """``transform={"placement": "tuned" | "separate" | "auto"}``, else ``$FEINSUM_PLACEMENT``, else "auto": tuned when
+    the launch writes several large streams (the arrays are ``timeit``'s own, so where they lie is its business:
+    DESIGN.md section 3d -- with one allocation per array the same launch times 0.195 ... 0.242 ms by the luck of the
+    allocator, placed 0.190 ... 0.196).  Small problems (the reference's default long_dim_length = 1e5) are left alone:
+    the effect is 3 % there and the boundary too sharp to find by scanning."""
+    import os
+
+    mode = None
+    if isinstance(transform, Mapping):
+        mode = transform.get("placement")
+    mode = mode or os.environ.get("FEINSUM_PLACEMENT") or "auto"
+    if mode == "tuned":
+        return True
+    if mode != "auto":
+        return False
+    planes = []
+    for t in out_dict.values():
+        nbytes = t.numel() * t.element_size()
+        lead = t.shape[0] if t.dim() == 3 else 1          # [planes][E][Np] outputs are written plane by plane together
+        planes += [nbytes // max(lead, 1)] * max(lead, 1)
+    return len(planes) > 1 and min(planes) >= AUTO_PLACEMENT_MIN_PLANE_BYTES
+
+
 @dataclass(frozen=True)
 class TimingResult:
     """What :func:`timeit_details` measured (seconds are per launch)."""
@@ -559,7 +590,7 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
     # `transform={"prepared": True}`: the operator matrices are written once in fragment layout (see
     # _FamilyLaunch.prepare_operators) instead of being rebuilt by every launch
     prepare = _prepared_from_transform(transform, False)
-    if isinstance(transform, Mapping) and transform.get("placement") == "tuned":
+    if _wants_tuned_placement(transform, out_dict):
         # the same arrays, moved into one arena at the position where the launch runs fastest (placement.py)
         from feinsum_amd import placement
 

@@ -33,6 +33,28 @@ def test_split_order_puts_one_cut_through_every_stage():
     assert placement.split_order([]) == []
 
 
+def test_placement_mode_of_timeit(monkeypatch):
+    """Which launches ``timeit`` places itself (measure._wants_tuned_placement): explicit requests, the environment, and by
+    default only launches that write several streams of at least 128 MiB."""
+    import torch
+
+    from feinsum_amd import measure
+
+    big3 = {"_fe_out": torch.empty((3, 600_000, 35), dtype=torch.float64, device="meta")}
+    big1 = {"_fe_out": torch.empty((600_000 * 3, 35), dtype=torch.float64, device="meta")}
+    four = {f"o{k}": torch.empty((600_000, 35), dtype=torch.float64, device="meta") for k in range(4)}
+    small = {"_fe_out": torch.empty((3, 100_000, 35), dtype=torch.float64, device="meta")}
+    monkeypatch.delenv("FEINSUM_PLACEMENT", raising=False)
+    assert measure._wants_tuned_placement(None, big3) and measure._wants_tuned_placement("mfma", four)
+    assert not measure._wants_tuned_placement(None, big1)          # one stream: nothing to split
+    assert not measure._wants_tuned_placement(None, small)         # the reference's default size
+    assert measure._wants_tuned_placement({"placement": "tuned"}, small)
+    assert not measure._wants_tuned_placement({"placement": "separate"}, big3)
+    monkeypatch.setenv("FEINSUM_PLACEMENT", "separate")
+    assert not measure._wants_tuned_placement(None, big3)
+    assert measure._wants_tuned_placement({"placement": "tuned"}, big3)
+
+
 @pytest.mark.gpu
 def test_tuned_layout_gives_the_same_results():
     import torch

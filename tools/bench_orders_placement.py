@@ -17,7 +17,7 @@ for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
         gops = f.count_ops(expr, long_dim_length=E) * 1e-9
         roof = f.get_roofline_flop_rate(expr, "AMD Instinct MI355X", E)[np.dtype("float64")]
         row = []
-        for what, tr in (("separate", {"variant": "mfma"}), ("tuned", {"variant": "mfma", "placement": "tuned"})):
+        for what, tr in (("separate", {"variant": "mfma", "placement": "separate"}), ("tuned", {"variant": "mfma", "placement": "tuned"})):
             r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
             row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")
         print(f"Np = {Np:2d} {name:14s} " + " | ".join(row), flush=True)

@@ -18,8 +18,8 @@ for name, expr in cases:
     gops = f.count_ops(expr, long_dim_length=E) * 1e-9
     roof = f.get_roofline_flop_rate(expr, "AMD Instinct MI355X", E)[np.dtype("float64")]
     row = []
-    for what, tr in (("separate", {"variant": "mfma"}), ("tuned", {"variant": "mfma", "placement": "tuned"}),
-                     ("separate", {"variant": "mfma"})):
+    for what, tr in (("separate", {"variant": "mfma", "placement": "separate"}), ("tuned", {"variant": "mfma", "placement": "tuned"}),
+                     ("separate", {"variant": "mfma", "placement": "separate"})):
         r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
         row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")
     print(f"Np = 56 {name:14s} " if not name.startswith("p4") else f"Np = 35 {name[3:]:14s} ", " | ".join(row), flush=True)
