@@ -367,6 +367,90 @@ def cpu_baseline(workload: str, budget_s: float = 8.0, full: bool = False):
 
 
 # --------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks
+# --------------------------------------------------------------------------
+
+def needs_own_ranks(gpus: int, environ) -> bool:
+    """True when this process was started plainly (no RANK / WORLD_SIZE from a launcher) but asked for several GPUs:
+    it then becomes the parent of N rank processes and touches no GPU itself."""
+    return gpus > 1 and "RANK" not in environ and "WORLD_SIZE" not in environ
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, *, script=None, environ=None, timeout_s: float = 3000.0, out=None, err=None) -> int:
+    """
+    Start *n* fresh rank processes of this script (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in their environment, as torch.distributed.run sets them), relay rank 0's standard output (the JSON
+    line), send the other ranks' standard output to our standard error, and return 0 only if every rank exited with 0.
+    The first rank that fails (or the timeout) ends the others -- by the PIDs started here, never by pattern.  The
+    parent makes no GPU call and replaces no process image: the ranks are children.
+    """
+    import subprocess
+    import threading
+
+    out = out or sys.stdout
+    err = err or sys.stderr
+    env0 = dict(os.environ if environ is None else environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(_free_port()))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    env0["FEINSUM_BENCH_LAUNCHER"] = "bench.py (self-spawned ranks)"
+    script = str(script or Path(__file__).resolve())
+    procs = []
+    for rank in range(n):
+        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env, stdout=subprocess.PIPE, stderr=None, text=True))
+
+    def relay(proc, sink):
+        for line in proc.stdout:
+            sink.write(line)
+            sink.flush()
+
+    threads = [threading.Thread(target=relay, args=(p_, out if r == 0 else err), daemon=True) for r, p_ in enumerate(procs)]
+    for t in threads:
+        t.start()
+    deadline = time.monotonic() + timeout_s
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p_ in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p_.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = (r, codes[r])
+        if failed is not None or time.monotonic() > deadline:
+            break
+        time.sleep(0.05)
+    if any(c is None for c in codes):      # a rank failed or the time ran out: end the ranks that are still running
+        why = f"rank {failed[0]} exited with {failed[1]}" if failed else f"no result after {timeout_s:.0f} s"
+        err.write(f"bench.py: {why}; stopping the other ranks\n")
+        for r, p_ in enumerate(procs):
+            if codes[r] is None:
+                p_.terminate()
+        for r, p_ in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = p_.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p_.kill()
+                    codes[r] = p_.wait()
+    for t in threads:
+        t.join(timeout=5)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        err.write(f"bench.py: ranks with a non-zero exit code: {bad}\n")
+        return 1
+    return 0
+
+
+# --------------------------------------------------------------------------
 
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -397,7 +481,14 @@ def main() -> None:
     ap.add_argument("--gather-fields", choices=("auto", "on", "off"), default="auto",
                     help="after the timed region: all-gather every output field over the ranks and report the rate "
                          "(SURVEY 8e's optional full-field exchange; auto = when there is more than one rank)")
+    ap.add_argument("--spawn-timeout", type=float, default=3000.0,
+                    help="--gpus N started without a launcher: seconds the N rank processes may take")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without RANK / WORLD_SIZE: this process becomes the parent of N ranks (no torch.cuda, no
+    # HIP call here) and exits with their verdict; under torch.distributed.run the ranks arrive with their environment set
+    if needs_own_ranks(args.gpus, os.environ):
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], timeout_s=args.spawn_timeout))
 
     import torch
 
@@ -406,7 +497,7 @@ def main() -> None:
 
     info = parallel.init_distributed()
     if info.world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {info.world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = torch.device("cuda", info.local_rank)
@@ -562,8 +653,11 @@ def main() -> None:
 
     # flops of the whole job = sum over ranks (ranks may hold different element counts)
     flops_all = flops_step
+    ranks_seen = 1
     if parallel.in_group():
         import torch.distributed as dist
+
+        ranks_seen = dist.get_world_size()
 
         t = torch.tensor([flops_step], dtype=torch.float64,
                          device="cpu" if dist.get_backend() == "gloo" else device)
@@ -575,7 +669,12 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
-                 "dist_backend": info.backend if parallel.in_group() else None, "field_allgather": field_gather}
+                 "dist_backend": info.backend if parallel.in_group() else None, "field_allgather": field_gather,
+                 # how many ranks the process group really holds (1 without a group), and who started them
+                 "ranks_seen": ranks_seen,
+                 "launcher": os.environ.get("FEINSUM_BENCH_LAUNCHER") or
+                             ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                              "external" if "WORLD_SIZE" in os.environ else "single process")}
         if protocol_ms is not None:
             extra["protocol_ms_per_step"] = round(protocol_ms["device"], 5)
             extra["protocol"] = {"what": "reference timing protocol (src/feinsum/measure.py:248-275): 5 warm-ups, "

@@ -40,6 +40,12 @@
 // leave no LDS room for a second buffer at 8 waves/CU; instead ALL B fragments of a tile are
 // computed up front, which frees the u buffer, and the next tile's loads are issued before
 // this tile's MFMAs and stores.
+// Arithmetic is position independent: every VALU contraction beside the MFMAs (B fragments  Ju = sum_x J u, the
+// MODE 4 / 5 epilogues) is written as one multiply followed by explicit fused multiply-adds, so the compiler has no
+// contraction choice to make differently for a wave's first (peeled) tile and its later ones -- round 2's plain
+// `a * b + c * d` was contracted differently there, and a tile's bits depended on its place in the walk, i.e. on E
+// and the CU count.  Only the elements behind the last full tile (remainder_items: scalar loop) are summed in
+// another order.
 #pragma once
 #include "fe_grad.h"
 
@@ -277,7 +283,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     const int j = 4 * jq + g;
                     const double v = j < NP ? up[tile_index<NP>(n, j < NP ? j : 0)] : 0.0;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) bfrag[jq][r] = x == 0 ? jac[r] * v : bfrag[jq][r] + jac[x * 3 + r] * v;
+                    for (int r = 0; r < 3; ++r) bfrag[jq][r] = x == 0 ? jac[r] * v : __builtin_fma(jac[x * 3 + r], v, bfrag[jq][r]);
                 }
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq)
@@ -442,7 +448,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     for (int qq = 0; qq < 4; ++qq) {
                         double v = jk[x * ND] * acc[0][t][qq];
 #pragma unroll
-                        for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * acc[r][t][qq];
+                        for (int r = 1; r < ND; ++r) v = __builtin_fma(jk[x * ND + r], acc[r][t][qq], v);
                         ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = v;
                     }
 #pragma unroll
@@ -450,7 +456,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     const int i = 16 * G::BT + 4 * q + g;
                     double v = jk[x * ND] * accs[0][q];
 #pragma unroll
-                    for (int r = 1; r < ND; ++r) v += jk[x * ND + r] * accs[r][q];
+                    for (int r = 1; r < ND; ++r) v = __builtin_fma(jk[x * ND + r], accs[r][q], v);
                     if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = v;
                 }
                 wave_lds_fence();
@@ -563,7 +569,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     } else {
                         double v = jac[r] * ux[0];
 #pragma unroll
-                        for (int x = 1; x < ND; ++x) v += jac[x * ND + r] * ux[x];
+                        for (int x = 1; x < ND; ++x) v = __builtin_fma(jac[x * ND + r], ux[x], v);   // explicit fma: see the note at the top
                         bfrag[m][jq][r] = v;
                     }
                 }
@@ -617,7 +623,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                         for (int qq = 0; qq < 4; ++qq) {
                             double v = jkeep[m][x * ND] * acc[0][t][qq];
 #pragma unroll
-                            for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * acc[r][t][qq];
+                            for (int r = 1; r < ND; ++r) v = __builtin_fma(jkeep[m][x * ND + r], acc[r][t][qq], v);
                             ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = v;
                         }
 #pragma unroll
@@ -625,7 +631,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                         const int i = 16 * G::BT + 4 * q + g;
                         double v = jkeep[m][x * ND] * accs[0][q];
 #pragma unroll
-                        for (int r = 1; r < ND; ++r) v += jkeep[m][x * ND + r] * accs[r][q];
+                        for (int r = 1; r < ND; ++r) v = __builtin_fma(jkeep[m][x * ND + r], accs[r][q], v);
                         if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = v;
                     }
                     wave_lds_fence();

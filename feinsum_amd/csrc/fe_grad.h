@@ -383,7 +383,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                     const double t0 = acc[(s + 0) >> 2][(s + 0) & 3];
                     const double t1 = acc[(s + 1) >> 2][(s + 1) & 3];
                     const double t2 = acc[(s + 2) >> 2][(s + 2) & 3];
-                    const double v = j0 * t0 + j1 * t1 + j2 * t2;
+                    const double v = __builtin_fma(j2, t2, __builtin_fma(j1, t1, j0 * t0));   // explicit: no contraction choice left to the compiler
                     const int i = G::TG * g + k;
                     if (G::TG * 3 + k < NP || i < NP) ob[n * NP + i] = v;
                 }

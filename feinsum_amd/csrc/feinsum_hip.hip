@@ -119,9 +119,22 @@ unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 25
 
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
+#ifndef FE_GRID_MODE
+#define FE_GRID_MODE 0
+#endif
 unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
     int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
     const int64_t cap = (8 / wavesPerBlock) * (int64_t)device_cu_count();   // 8 waves per CU
+#if FE_GRID_MODE == 1
+    // experiment: every wave walks the same number of tiles k = ceil(nTiles / resident waves), on
+    // ceil(nTiles / k) waves -- no last round on a fraction of the machine (E = 1e5: 1563 waves x 4 tiles instead of
+    // 106 x 4 + 1942 x 3)
+    if (blocks > cap) {
+        const int64_t k = (nTiles + cap * wavesPerBlock - 1) / (cap * wavesPerBlock);
+        const int64_t waves = (nTiles + k - 1) / k;
+        blocks = (waves + wavesPerBlock - 1) / wavesPerBlock;
+    }
+#endif
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
