@@ -24,11 +24,11 @@ Argument conventions kept from the reference:
                (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
                a variant explicitly; in a dict, ``"prepared": True`` lets a
                bound launch (``timeit``) use a prepared copy of its operator
-               matrices; ``"placement"``: ``"tuned"`` makes ``timeit`` place the
-               arrays where the launch runs fastest (``feinsum_amd.placement``),
-               ``"separate"`` keeps one allocation per array, the default
-               ``"auto"`` (or ``$FEINSUM_PLACEMENT``) tunes when the launch
-               writes several streams of >= 128 MiB each.
+               matrices; ``"placement"`` (or ``$FEINSUM_PLACEMENT``): the default
+               ``"separate"`` times one allocation per array, as the reference
+               does; ``"tuned"`` is opt-in and makes ``timeit`` place its arrays
+               where the launch runs fastest (``feinsum_amd.placement``);
+               ``timeit_details(...).placement`` reports which was used.
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -38,7 +38,7 @@ order** (the reference draws in hash order, which is not reproducible; SURVEY H5
 from __future__ import annotations
 
 import logging
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from time import time
 from types import MappingProxyType
 from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
@@ -537,32 +537,26 @@ def validate_batched_einsum_transform(einsum: BatchedEinsum, cq: Any, transform:
     logger.info("Statistically verified the soundness of the transformation")
 
 
-#: a written array (or plane of one) of at least this size makes ``timeit`` place the arrays itself by default
-AUTO_PLACEMENT_MIN_PLANE_BYTES = 128 << 20
+PLACEMENT_MODES = ("separate", "tuned")
 
 
-def _wants_tuned_placement(transform: Any, out_dict: Mapping[str, Any]) -> bool:
-    """``transform={"placement": "tuned" | "separate" | "auto"}``, else ``$FEINSUM_PLACEMENT``, else "auto": tuned when
-    the launch writes several large streams (the arrays are ``timeit``'s own, so where they lie is its business:
-    DESIGN.md section 3d -- with one allocation per array the same launch times 0.195 ... 0.242 ms by the luck of the
-    allocator, placed 0.190 ... 0.196).  Small problems (the reference's default long_dim_length = 1e5) are left alone:
-    the effect is 3 % there and the boundary too sharp to find by scanning."""
+def _placement_mode(transform: Any) -> str:
+    """
+    Where ``timeit`` puts its arrays: ``transform={"placement": ...}``, else ``$FEINSUM_PLACEMENT``, else
+    ``"separate"`` -- one allocation per array, the reference's protocol (``src/feinsum/measure.py:44-60,80-108``)
+    and what a caller of :func:`evaluate` gets on arrays of its own.  ``"tuned"`` is opt-in: the arrays are carved out
+    of one large arena at the position where the launch times fastest (``feinsum_amd/placement.py``, DESIGN.md
+    section 3d); the number it yields holds for arrays placed that way only, and the :class:`TimingResult` says so.
+    """
     import os
 
-    mode = None
-    if isinstance(transform, Mapping):
-        mode = transform.get("placement")
-    mode = mode or os.environ.get("FEINSUM_PLACEMENT") or "auto"
-    if mode == "tuned":
-        return True
-    if mode != "auto":
-        return False
-    planes = []
-    for t in out_dict.values():
-        nbytes = t.numel() * t.element_size()
-        lead = t.shape[0] if t.dim() == 3 else 1          # [planes][E][Np] outputs are written plane by plane together
-        planes += [nbytes // max(lead, 1)] * max(lead, 1)
-    return len(planes) > 1 and min(planes) >= AUTO_PLACEMENT_MIN_PLANE_BYTES
+    mode = transform.get("placement") if isinstance(transform, Mapping) else None
+    mode = mode or os.environ.get("FEINSUM_PLACEMENT") or "separate"
+    if mode == "auto":          # round 2's default; kept as a synonym of the reference-faithful mode
+        mode = "separate"
+    if mode not in PLACEMENT_MODES:
+        raise InvalidParameterError(f"placement must be one of {PLACEMENT_MODES}, got {mode!r}")
+    return mode
 
 
 @dataclass(frozen=True)
@@ -572,6 +566,10 @@ class TimingResult:
     seconds_device: float     # HIP-event time per launch (what timeit returns)
     seconds_wall: float       # host wall-clock per launch, reference protocol
     rounds: int
+    #: how the timed arrays were placed: {"mode": "separate"} (one allocation per array, the reference's protocol) or
+    #: the report of placement.tune_base_retry ({"mode": "tuned", arena size, positions scanned, whether a class
+    #: boundary was found, ...}); a tuned placement that could not be had says so under "fallback"
+    placement: Mapping[str, Any] = field(default_factory=lambda: MappingProxyType({"mode": "separate"}))
 
 
 def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = None,
@@ -590,14 +588,17 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
     # `transform={"prepared": True}`: the operator matrices are written once in fragment layout (see
     # _FamilyLaunch.prepare_operators) instead of being rebuilt by every launch
     prepare = _prepared_from_transform(transform, False)
-    if _wants_tuned_placement(transform, out_dict):
+    report: Mapping[str, Any] = {"mode": "separate"}
+    if _placement_mode(transform) == "tuned":
         # the same arrays, moved into one arena at the position where the launch runs fastest (placement.py)
         from feinsum_amd import placement
 
         names = sorted(arg_dict)
+        out_names = list(out_dict)
         arrays = [(n, tuple(arg_dict[n].shape), arg_dict[n].dtype) for n in names] \
             + [(n, tuple(t.shape), t.dtype) for n, t in out_dict.items()]
         staged = dict(arg_dict)
+        out_dict = None               # the outputs need no staging (zero-filled views): do not hold them twice
 
         def fill(name, view):
             if name in staged:
@@ -606,13 +607,19 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
                 view.zero_()
 
         def make_step(views):
-            _, b, _ = _bind(einsum, q, {n: views[n] for n in names}, {n: views[n] for n in out_dict}, transform,
+            _, b, _ = _bind(einsum, q, {n: views[n] for n in names}, {n: views[n] for n in out_names}, transform,
                             prepare=prepare)
             return lambda n: b.time_batch(n, q.stream_ptr)
 
-        with torch.cuda.device(q.torch_device):
-            arena, views, _report = placement.tune_base_retry(arrays, q.torch_device, make_step, fill=fill, attempts=2)
-        arg_dict, out_dict = {n: views[n] for n in names}, {n: views[n] for n in out_dict}
+        try:
+            with torch.cuda.device(q.torch_device):
+                arena, views, report = placement.tune_base_retry(arrays, q.torch_device, make_step, fill=fill, attempts=2)
+            arg_dict, out_dict = {n: views[n] for n in names}, {n: views[n] for n in out_names}
+        except torch.cuda.OutOfMemoryError as exc:
+            # no room for an arena beside the caller's data: time the separately allocated arrays, and say so
+            logger.warning("tuned placement not available (%s); timing separately allocated arrays", str(exc)[:120])
+            report = {"mode": "separate", "fallback": f"tuned placement asked for, arena allocation failed: {str(exc)[:160]}"}
+            out_dict = generate_out_arrays(q, einsum, long_dim_length)
         del staged
     _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=prepare)
     with torch.cuda.device(q.torch_device):
@@ -626,7 +633,7 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
             dev_time += bound.time_batch(LAUNCHES_PER_BATCH, q.stream_ptr)   # fences like evt.wait()
             wall_time += time() - t0
             rounds += LAUNCHES_PER_BATCH
-    return TimingResult(dev_time / rounds, wall_time / rounds, rounds)
+    return TimingResult(dev_time / rounds, wall_time / rounds, rounds, MappingProxyType(dict(report)))
 
 
 def timeit(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = None,

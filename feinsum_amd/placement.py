@@ -226,6 +226,5 @@ def tune_base_retry(arrays: Sequence[Tuple[str, Tuple[int, ...], Any]], device: 
         if report["class_boundary_found"]:
             break
     kept[2]["arenas_tried"] = len(held) + 1
-    del held
-    torch.cuda.empty_cache()
+    del held        # back to the caller's caching allocator (not emptied here: the cache is the caller's)
     return kept

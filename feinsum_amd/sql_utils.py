@@ -11,7 +11,8 @@ read a database written here; what differs is what the columns *mean*:
 ``transform_id``      the reference stores the file name of a loopy transform
                       (``xre_rij_ej_to_xei.py``); here it is the name of a kernel
                       variant of ``libfeinsum_hip.so`` (``"mfma"``, ``"generic"``).
-``transform_params``  parameters of that variant (none so far: ``{}``).
+``transform_params``  what else parametrises the measurement: ``placement`` (how ``timeit`` placed its arrays:
+                      ``"separate"`` = one allocation per array; with ``"tuned"`` also ``placement_report``).
 ``compiler_version``  ``"AMD-ROCm <hip version>"`` instead of the OpenCL vendor/driver.
 keys                  the einsum is keyed by the canonical form of
                       ``feinsum_amd.canonicalization`` (exhaustive search), not by the
@@ -258,10 +259,18 @@ def record_facts(einsum: BatchedEinsum, cq: Any, variant: str = "mfma",
         raise ValueError(f"unknown kernel variant '{variant}' (known: {KNOWN_VARIANTS})")
     einsum = canonicalize_einsum(einsum)
     if runtime_in_sec is None:
-        from feinsum_amd.measure import _as_queue, timeit
+        from feinsum_amd.measure import _as_queue, timeit_details
 
-        runtime_in_sec = timeit(einsum, cq=cq, transform={"variant": variant, **params},
+        timing = timeit_details(einsum, cq=cq, transform={"variant": variant, **params},
                                 long_dim_length=long_dim_length)
+        runtime_in_sec = timing.seconds_device
+        # how the timed arrays were placed is part of the fact (transform_params is the reference's JSON column for
+        # what parametrises a measurement): "separate" = one allocation per array, what evaluate() callers get
+        params["placement"] = timing.placement.get("mode", "separate")
+        if timing.placement.get("mode") == "tuned":
+            params["placement_report"] = {k: timing.placement[k] for k in
+                                          ("class_boundary_found", "arenas_tried", "scan_positions", "scan_median_ms", "best_ms")
+                                          if k in timing.placement}
         device_name = device_name or _as_queue(cq).device.name
     if device_name is None:
         raise ValueError("device_name is needed with an external runtime_in_sec")

@@ -486,6 +486,27 @@ def test_full_size_div_and_face_mass(torch_cuda, fam):
     scaled[vname] = dev[vname] * 2.0
     outs2 = f.evaluate(expr, 0, scaled, wait=True)
     assert torch.equal(outs2["_fe_out"], outs["_fe_out"] * 2.0)
+    # position independence (as for grad in test_full_size_linearity_and_locality): a tile-aligned sub-batch evaluated
+    # alone, and the whole batch with its elements permuted, give the same bits per element -- a tile's arithmetic does
+    # not depend on where it falls in a wave's walk, hence not on E or the CU count
+    def restricted(index):
+        sub = {}
+        for name, t in dev.items():
+            idx = tuple(index if isinstance(d, f.SizeParam) else slice(None) for d in expr.arg_to_shape[name])
+            sub[name] = t[idx].contiguous()
+        return sub
+
+    s0, n = 16 * 4321, 16 * 700
+    part = f.evaluate(expr, 0, restricted(slice(s0, s0 + n)), wait=True)
+    for k in outs:
+        assert torch.equal(part[k], outs[k][s0:s0 + n]), k
+    perm = torch.randperm(E, device="cuda")
+    permuted = f.evaluate(expr, 0, restricted(perm), wait=True)
+    for k in outs:
+        assert torch.equal(permuted[k], outs[k][perm]), k
+    again = f.evaluate(expr, 0, dev, wait=True)
+    for k in outs:
+        assert torch.equal(again[k], outs[k]), k
 
 
 FULL_SIZE_SIBLINGS = {
@@ -664,8 +685,9 @@ def test_config5_eight_million_elements(torch_cuda):
 def test_div_split_walk_matches_the_mfma_kernel(torch_cuda, Np, E):
     """FE_VARIANT_MFMA_SPLIT ("mfma_split"): div walking both halves of the element range at once -- the same tiles, the
     same arithmetic, another order (odd and even tile counts, a remainder behind the last tile, several tiles per wave
-    at E = 70 003), single and batched.  Equal to the plain walk to the last bit or two: the compiler contracts the
-    first tile of a wave differently from its later ones, and which tile comes first differs between the walks."""
+    at E = 70 003), single and batched.  BITWISE equal to the plain walk: the VALU contractions are explicit fused
+    multiply-adds (round 3), so a tile's bits do not depend on its place in a wave's walk (round 2 had to relax this to
+    rtol 1e-14: the compiler contracted a wave's first tile differently from its later ones)."""
     torch = torch_cuda
     for expr in (dg.div(Np), dg.batched_div(3, Np)):
         dev = _device_inputs(torch, expr, E, seed=E + Np)
@@ -674,7 +696,7 @@ def test_div_split_walk_matches_the_mfma_kernel(torch_cuda, Np, E):
         generic = f.evaluate(expr, 0, dev, transform="generic", wait=True)
         assert set(plain) == set(split)
         for name in plain:
-            assert torch.allclose(plain[name], split[name], rtol=1e-14, atol=0.0), (name, Np, E)
+            assert torch.equal(plain[name], split[name]), (name, Np, E)
             assert torch.allclose(generic[name], split[name], rtol=1e-12, atol=0.0), (name, Np, E)
 
 

@@ -144,3 +144,6 @@ def test_timeit_options_prepared_and_tuned_placement():
                                      transform={"variant": "mfma", "placement": "tuned"})
     for t in (t_plain, t_prep, t_tuned):
         assert 0 < t.seconds_device < 1e-3
+    # the result says how its arrays were placed (a recorded fact must be reproducible by a caller)
+    assert t_plain.placement["mode"] == "separate" and t_prep.placement["mode"] == "separate"
+    assert t_tuned.placement["mode"] == "tuned" and "class_boundary_found" in t_tuned.placement

@@ -34,25 +34,22 @@ def test_split_order_puts_one_cut_through_every_stage():
 
 
 def test_placement_mode_of_timeit(monkeypatch):
-    """Which launches ``timeit`` places itself (measure._wants_tuned_placement): explicit requests, the environment, and by
-    default only launches that write several streams of at least 128 MiB."""
-    import torch
-
+    """``timeit`` times one allocation per array unless asked otherwise (the reference's protocol is the
+    default; a tuned arena is opt-in through the transform or the environment)."""
     from feinsum_amd import measure
+    from feinsum_amd.diagnostics import InvalidParameterError
 
-    big3 = {"_fe_out": torch.empty((3, 600_000, 35), dtype=torch.float64, device="meta")}
-    big1 = {"_fe_out": torch.empty((600_000 * 3, 35), dtype=torch.float64, device="meta")}
-    four = {f"o{k}": torch.empty((600_000, 35), dtype=torch.float64, device="meta") for k in range(4)}
-    small = {"_fe_out": torch.empty((3, 100_000, 35), dtype=torch.float64, device="meta")}
     monkeypatch.delenv("FEINSUM_PLACEMENT", raising=False)
-    assert measure._wants_tuned_placement(None, big3) and measure._wants_tuned_placement("mfma", four)
-    assert not measure._wants_tuned_placement(None, big1)          # one stream: nothing to split
-    assert not measure._wants_tuned_placement(None, small)         # the reference's default size
-    assert measure._wants_tuned_placement({"placement": "tuned"}, small)
-    assert not measure._wants_tuned_placement({"placement": "separate"}, big3)
-    monkeypatch.setenv("FEINSUM_PLACEMENT", "separate")
-    assert not measure._wants_tuned_placement(None, big3)
-    assert measure._wants_tuned_placement({"placement": "tuned"}, big3)
+    assert measure._placement_mode(None) == "separate" and measure._placement_mode("mfma") == "separate"
+    assert measure._placement_mode({"variant": "mfma"}) == "separate"
+    assert measure._placement_mode({"placement": "tuned"}) == "tuned"
+    assert measure._placement_mode({"placement": "auto"}) == "separate"       # round 2's default name
+    monkeypatch.setenv("FEINSUM_PLACEMENT", "tuned")
+    assert measure._placement_mode(None) == "tuned"
+    assert measure._placement_mode({"placement": "separate"}) == "separate"   # the transform wins over the environment
+    with pytest.raises(InvalidParameterError):
+        measure._placement_mode({"placement": "somewhere"})
+    assert measure.TimingResult(1e-3, 1e-3, 10).placement["mode"] == "separate"
 
 
 @pytest.mark.gpu
