@@ -472,9 +472,11 @@ def main() -> None:
     ap.add_argument("--prepare", action="store_true",
                     help="prepare the operator matrices once at bind time (fe_prepare_operator) instead of rebuilding the "
                          "MFMA fragments in every launch; measured: no gain, see DESIGN.md")
-    ap.add_argument("--placement", default="tuned", choices=["tuned", "separate"],
-                    help="tuned: all arrays in one large arena, at the position that times fastest "
-                         "(feinsum_amd/placement.py); separate: one torch allocation per array")
+    ap.add_argument("--placement", default="split", choices=["split", "separate", "tuned"],
+                    help="split (default): one allocation per array, the OUTPUTS from the split allocator "
+                         "(feinsum_amd.placement.zeros: halves in different classes of physical memory; no arena, no scan); "
+                         "separate: every array from torch; tuned (round 2): all arrays in one large arena, at the "
+                         "position that times fastest")
     ap.add_argument("--arena-gib", type=float, default=66.0, help="size of the placement arena (tuned placement)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
@@ -489,6 +491,10 @@ def main() -> None:
     # HIP call here) and exits with their verdict; under torch.distributed.run the ranks arrive with their environment set
     if needs_own_ranks(args.gpus, os.environ):
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], timeout_s=args.spawn_timeout))
+
+    # a kernel that compiled to fewer resident blocks per CU than its launch geometry assumes is an error here, not a
+    # warning (feinsum_hip.hip: configure_kernel): a number taken at half the residency is not the product's
+    os.environ.setdefault("FEINSUM_STRICT_RESIDENCY", "1")
 
     import torch
 
@@ -512,16 +518,17 @@ def main() -> None:
     if len(exprs) > 1:                   # J and D counted once
         bytes_step -= 8.0 * (9 * E + 3 * NP * NP)
 
-    # div alone in the tuned placement: its one output array gets two write windows (FE_VARIANT_MFMA_SPLIT), which the
-    # class boundary the placement puts into the middle of that array then splits
-    variant = "mfma_split" if (args.variant == "auto" and args.workload == "div" and args.placement == "tuned") else args.variant
+    # (div's two-window walk, FE_VARIANT_MFMA_SPLIT, is an explicit choice: --variant mfma_split; it pays when the output
+    # array is cut across two classes of physical memory in the middle, which is how the split allocator lays arrays out)
+    variant = args.variant
 
     def bind(stages, out_dicts, variant_=None):
         return operator.bind_operator(stages, q, out_dicts=out_dicts, transform=variant_ or variant, fuse=not args.no_fuse,
                                       prepare=args.prepare)
 
-    def separate_allocations():
-        """One torch allocation per array (what round 1 measured)."""
+    def separate_allocations(split=False):
+        """One allocation per array: inputs from torch, outputs from torch (what round 1 measured) or, *split*, from
+        the split allocator."""
         stages, out_dicts, shared = [], [], {}
         for k, expr in enumerate(exprs):
             dev = _device_inputs(expr, E, device, seed=1000 * info.rank + k)
@@ -529,7 +536,7 @@ def main() -> None:
                 if name in dev:
                     dev[name] = shared.setdefault(name, dev[name])
             stages.append((expr, dev))
-            out_dicts.append(measure.generate_out_arrays(q, expr, E))
+            out_dicts.append(measure.generate_out_arrays(q, expr, E, split=split))
         return stages, out_dicts
 
     def step_batch_of(op_):
@@ -578,6 +585,28 @@ def main() -> None:
             **({"stride_mib": 64, "fine_step_mib": 16, "coarse_launches": 6} if variant == "mfma_split" else {}),
             arena_gib=args.arena_gib / max(1, info.world_size if os.environ.get("FEINSUM_DIST_BACKEND") == "gloo" else 1))
         stages, out_dicts = stages_of(views)
+    elif args.placement == "split":
+        from feinsum_amd import placement
+
+        t_alloc = time.perf_counter()
+        stages, out_dicts = separate_allocations(split=True)
+        sync()
+        t_alloc = (time.perf_counter() - t_alloc) * 1e3
+        infos = [placement.split_info(t) for od in out_dicts for t in od.values()]
+        pool = placement.split_stats(device)
+        placement_report = {
+            "mode": "split",
+            "what": "one allocation per array; outputs from the split allocator (fe_split_alloc: 128 MiB pieces classified by a "
+                    "two-stream write probe, first half of an array in one class of physical memory, second half in another; "
+                    "no arena, no timing scan)",
+            "output_piece_classes": [i.get("classes", "torch allocation (below 256 MiB)") for i in infos],
+            "output_bytes": sum(int(t.numel()) * t.element_size() for od in out_dicts for t in od.values()),
+            "output_mapped_bytes": sum(i.get("mapped_bytes", 0) for i in infos),
+            "allocator_ms": round(pool["setup_ms"] + pool["alloc_ms_total"], 3),
+            "inputs_and_outputs_ready_ms": round(t_alloc, 1),
+            "pool": {k: pool[k] for k in ("classes", "pieces_created", "probes", "spacers_created", "spacer_bytes_peak",
+                                            "unsplit_arrays", "pooled_bytes", "walk_gave_up")},
+        }
     else:
         stages, out_dicts = separate_allocations()
     outs_all = [t for od in out_dicts for t in od.values()]
@@ -619,8 +648,8 @@ def main() -> None:
 
     # A/B outside the timed region: the same launch on one-torch-allocation-per-array operands
     separate_ms = None
-    if args.placement == "tuned" and not args.no_protocol:
-        op_sep = bind(*separate_allocations(), variant_=args.variant)     # (the plain walk: what a caller gets by default)
+    if args.placement != "separate" and not args.no_protocol:
+        op_sep = bind(*separate_allocations(), variant_=args.variant)
         sb = step_batch_of(op_sep)
         sb(max(args.warmup, 10))
         separate_ms = sb(args.steps) / args.steps * 1e3

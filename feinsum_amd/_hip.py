@@ -34,7 +34,8 @@ EXPORTED_SYMBOLS = (
     "fe_facemass_f64",
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
-    "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64",
+    "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
+    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim",
 )
 
 _c_double_p = C.c_void_p   # device pointers travel as plain integers
@@ -144,6 +145,18 @@ def load_library() -> C.CDLL:
     lib.fe_divcomp_f64.restype = C.c_int
     lib.fe_divcomp_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fe_release_prepared.restype = C.c_int
+    lib.fe_release_prepared.argtypes = [C.c_void_p]
+    lib.fe_split_alloc.restype = C.c_int
+    lib.fe_split_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int32]
+    lib.fe_split_free.restype = C.c_int
+    lib.fe_split_free.argtypes = [C.c_void_p]
+    lib.fe_split_info.restype = C.c_int
+    lib.fe_split_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.fe_split_stats.restype = C.c_int
+    lib.fe_split_stats.argtypes = [C.c_char_p, C.c_size_t]
+    lib.fe_split_trim.restype = C.c_int
+    lib.fe_split_trim.argtypes = []
     lib.fe_prepare_operator.restype = C.c_int
     lib.fe_prepare_operator.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]
@@ -301,6 +314,46 @@ def prepare_operator(family: int, op: int, Np: int, nf: int, Nfp: int, flags: in
     """Write operator *op* in the kernels' fragment layout into the device buffer *prepared*
     (PREPARED_OPERATOR_BYTES bytes).  NotImplementedError: this shape has no prepared form."""
     check(load_library().fe_prepare_operator(family, op, Np, nf, Nfp, flags, prepared, stream))
+
+
+def release_prepared(prepared: int) -> None:
+    """Drop the library's record of a prepared-operator buffer (before the buffer is freed)."""
+    check(load_library().fe_release_prepared(prepared))
+
+
+def split_alloc(nbytes: int) -> int:
+    """Device pointer of a new array of the split allocator on the CURRENT device (fe_split_alloc)."""
+    ptr = C.c_void_p()
+    check(load_library().fe_split_alloc(C.byref(ptr), nbytes, 0))
+    return int(ptr.value)
+
+
+def split_free(ptr: int) -> None:
+    check(load_library().fe_split_free(ptr))
+
+
+def _json_call(fn, *args) -> dict:
+    import json
+
+    buf = C.create_string_buffer(1 << 14)
+    n = fn(*args, buf, len(buf))
+    if n < 0:
+        check(n)
+    return json.loads(buf.value.decode())
+
+
+def split_info(ptr: int) -> dict:
+    """What the split allocator did for one array: bytes, mapped bytes, class of every piece, milliseconds."""
+    return _json_call(load_library().fe_split_info, ptr)
+
+
+def split_stats() -> dict:
+    """The current device's pool of the split allocator."""
+    return _json_call(load_library().fe_split_stats)
+
+
+def split_trim() -> None:
+    check(load_library().fe_split_trim())
 
 
 def kernel_resources() -> str:

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -81,11 +82,30 @@ int configure_kernel(K kernel, const char* what, int lds_bytes, int threads, int
         std::lock_guard<std::mutex> lock(g_resources_mutex);
         g_resources += line;
     }
-    if (resident < blocks_per_cu)
-        return fail(FE_EHIP, "%s: %d block(s) of %d threads fit a CU but the launch geometry assumes %d "
-                    "(%d VGPRs, %d B of LDS per block): the compiled kernel's register or LDS use grew",
-                    what, resident, threads, blocks_per_cu, attr.numRegs, lds_bytes);
+    if (resident < blocks_per_cu) {
+        // The launch is still correct (the surplus blocks queue behind the resident ones), only slower: by default this
+        // is a WARNING line in fe_kernel_resources().  FEINSUM_STRICT_RESIDENCY=1 (the test suite and bench.py set it)
+        // turns it into FE_EHIP, so that a compiler regression cannot pass with green tests at half the speed.
+        char line[320];
+        snprintf(line, sizeof(line), "WARNING %s: %d block(s) of %d threads fit a CU but the launch geometry assumes %d "
+                 "(%d VGPRs, %d B of LDS per block): the compiled kernel's register or LDS use grew\n",
+                 what, resident, threads, blocks_per_cu, attr.numRegs, lds_bytes);
+        {
+            std::lock_guard<std::mutex> lock(g_resources_mutex);
+            g_resources += line;
+        }
+        const char* strict = getenv("FEINSUM_STRICT_RESIDENCY");
+        if (strict && strict[0] == '1') return fail(FE_EHIP, "%s", line + 8);
+    }
     return FE_OK;
+}
+
+// configure_kernel under the caller's once-flag: every kernel INSTANTIATION has a flag of its own, so that a
+// shortfall (or any other failure) of one instantiation -- say the opt-in prepared-operator one -- cannot fail the
+// launches of its siblings for the rest of the process.
+template <typename Once, typename K>
+int configured(Once& once, K kernel, const char* what, int lds_bytes, int threads, int blocks_per_cu) {
+    return once.run([&] { return configure_kernel(kernel, what, lds_bytes, threads, blocks_per_cu); });
 }
 
 // Kernel attributes are per device: a `static std::once_flag` per kernel would configure only
@@ -101,6 +121,10 @@ struct PerDeviceOnce {
         return rc[dev];
     }
 };
+
+}  // namespace
+#include "fe_split_alloc.h"
+namespace {
 
 int check_common(const void* J, const void* D, const void* u, const void* out, int64_t E,
                  int32_t Np) {
@@ -280,16 +304,23 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    static PerDeviceOnce once;
-    const int attr_rc = once.run([] {
-        char what[64];
-        snprintf(what, sizeof(what), "grad Np=%d M=%d", NP, M);
-        int rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, 2);
-        snprintf(what, sizeof(what), "grad Np=%d M=%d, prepared operator", NP, M);
-        if (rc == FE_OK) rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, true, true>, what, G::LDS_BYTES, 256, 2);
+    static PerDeviceOnce once_plain, once_prepared, once_planes;
+    char what[64];
+    const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
+    int attr_rc;
+    if (!plain) {
         snprintf(what, sizeof(what), "grad planes Np=%d M=%d", NP, M);
-        if (rc == FE_OK) rc = configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, false>, what, G::LDS_BYTES, 256, 2);
+        attr_rc = configured(once_planes, fe::grad3d_mfma_kernel<NP, M, 0, false>, what, G::LDS_BYTES, 256, 2);
+    } else if (gsec) {
+        snprintf(what, sizeof(what), "grad Np=%d M=%d, prepared operator", NP, M);
+        attr_rc = configured(once_prepared, fe::grad3d_mfma_kernel<NP, M, 0, true, true>, what, G::LDS_BYTES, 256, 2);
+    } else {
+        snprintf(what, sizeof(what), "grad Np=%d M=%d", NP, M);
+        attr_rc = configured(once_plain, fe::grad3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, 2);
+    }
 #ifdef FE_EXPERIMENTS
+    static PerDeviceOnce once_exp;
+    once_exp.run([] {
         if (NP == 35) {
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
@@ -298,13 +329,14 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 128>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, "grad (experiments build)", G::LDS_BYTES, 256, 2);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, true, true>, "grad prepared (experiments build)", G::LDS_BYTES, 256, 2);
         }
-#endif
-        return rc;
+        return FE_OK;
     });
+#endif
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
-    const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
     if (!plain) {   // general planes: per-plane geometry-factor and output pointers
         hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, false>), g, b, G::LDS_BYTES, s, P, D, nullptr, nb, nx, E,
                            nTiles, opT);
@@ -344,25 +376,29 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    static PerDeviceOnce once;
-    const int attr_rc = once.run([] {
-        char what[64];
-        snprintf(what, sizeof(what), "div Np=%d M=%d", NP, M);
-        int rc = configure_kernel(fe::div3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+    static PerDeviceOnce once_plain, once_prepared;
+    char what[64];
+    int attr_rc;
+    if (prep) {
         snprintf(what, sizeof(what), "div Np=%d M=%d, prepared operator", NP, M);
-        if (rc == FE_OK)
-            rc = configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, 0, 3, false, false, true>, what, G::LDS_BYTES, 256,
-                                  G::BLOCKS_PER_CU);
+        attr_rc = configured(once_prepared, fe::div3d_mfma_kernel<NP, M, 0, 0, 3, false, false, true>, what, G::LDS_BYTES, 256,
+                             G::BLOCKS_PER_CU);
+    } else {
+        snprintf(what, sizeof(what), "div Np=%d M=%d", NP, M);
+        attr_rc = configured(once_plain, fe::div3d_mfma_kernel<NP, M, 0>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
+    }
 #ifdef FE_EXPERIMENTS
+    static PerDeviceOnce once_exp;
+    once_exp.run([] {
         if (NP == 35) {
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
         }
-#endif
-        return rc;
+        return FE_OK;
     });
+#endif
     if (attr_rc != FE_OK) return attr_rc;
     const dim3 g(persistent_grid(nTiles, G::WAVES)), b(256);
 #define FE_DIV_CASE(DBG) \
@@ -443,20 +479,22 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
     constexpr bool kCanPrep = !ALDS && NF == fe::kFmNf;   // prepared operators: tetrahedra p = 1..4
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
-    static PerDeviceOnce once;
-    const int attr_rc = once.run([] {
-        char what[80];
-        snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d nf=%d M=%d b=%d", NP, NFP, NF, M, NB);
-        int rc = configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, what, G::LDS_BYTES, G::THREADS,
-                                  G::BLOCKS_PER_CU);
+    static PerDeviceOnce once_plain, once_prepared;
+    char what[96];
+    int attr_rc = FE_OK;
+    bool use_prep = false;
+    if constexpr (kCanPrep) use_prep = prep != nullptr;
+    if (use_prep) {
         if constexpr (kCanPrep) {
             snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d M=%d b=%d, prepared operator", NP, NFP, M, NB);
-            if (rc == FE_OK)
-                rc = configure_kernel(fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>, what, G::LDS_BYTES,
-                                      G::THREADS, G::BLOCKS_PER_CU);
+            attr_rc = configured(once_prepared, fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>, what, G::LDS_BYTES,
+                                 G::THREADS, G::BLOCKS_PER_CU);
         }
-        return rc;
-    });
+    } else {
+        snprintf(what, sizeof(what), "face-mass Np=%d Nfp=%d nf=%d M=%d b=%d", NP, NFP, NF, M, NB);
+        attr_rc = configured(once_plain, fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>, what, G::LDS_BYTES, G::THREADS,
+                             G::BLOCKS_PER_CU);
+    }
     if (attr_rc != FE_OK) return attr_rc;
     int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
     const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
@@ -580,15 +618,16 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     const int64_t nTilesG = E / GG::TEL, nTilesD = E / GD::TEL;
     *e_done_g = *e_done_d = (nTilesG > 0 || nTilesD > 0) ? E : 0;   // remainders included
     if (nTilesG == 0 && nTilesD == 0) return FE_OK;
-    static PerDeviceOnce once;
-    const int attr_rc = once.run([] {
-        char what[64];
-        snprintf(what, sizeof(what), "div + grad Np=%d", NP);
-        int rc = configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+    static PerDeviceOnce once_plain, once_prepared;
+    char what[64];
+    int attr_rc;
+    if (prep) {
         snprintf(what, sizeof(what), "div + grad Np=%d, prepared operator", NP);
-        if (rc == FE_OK) rc = configure_kernel(fe::graddiv3d_mfma_kernel<NP, MG, MD, true>, what, G::LDS_BYTES, 256, 2);
-        return rc;
-    });
+        attr_rc = configured(once_prepared, fe::graddiv3d_mfma_kernel<NP, MG, MD, true>, what, G::LDS_BYTES, 256, 2);
+    } else {
+        snprintf(what, sizeof(what), "div + grad Np=%d", NP);
+        attr_rc = configured(once_plain, fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+    }
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
     const unsigned grid = persistent_grid(nTiles, 4);
@@ -610,16 +649,16 @@ template <int NP, int NFP, int MG, int MD, int MF, int NB>
 int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe::FieldPtrs& Pd,
                      const fe::FieldPtrs& Pf, hipStream_t s) {
     using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
-    static PerDeviceOnce once;
-    const int attr_rc = once.run([] {
-        char what[80];
-        snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
-        int rc = configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
+    static PerDeviceOnce once_plain, once_prepared;
+    char what[80];
+    int attr_rc;
+    if (a.prepD && a.prepR) {
         snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d, prepared operators", NP, NB);
-        if (rc == FE_OK)
-            rc = configure_kernel(fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>, what, G::LDS_BYTES, 256, 2);
-        return rc;
-    });
+        attr_rc = configured(once_prepared, fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>, what, G::LDS_BYTES, 256, 2);
+    } else {
+        snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
+        attr_rc = configured(once_plain, fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
+    }
     if (attr_rc != FE_OK) return attr_rc;
     int64_t nTiles = a.nTilesG > a.nTilesD ? a.nTilesG : a.nTilesD;
     if (a.nTilesF > nTiles) nTiles = a.nTilesF;
@@ -686,13 +725,13 @@ int launch_nd2_np(const double* J, const double* D, const fe::FieldPtrs& P, int 
 
 // ---- prepared operators: what fe_prepare_operator wrote where (host-side record, so that a launcher
 // can refuse a buffer prepared for another shape without reading device memory)
-struct PreparedInfo { int kind, Np, nf, Nfp, flags; };
+struct PreparedInfo { int kind, Np, nf, Nfp, flags; const void* op; int device; };   // op: the array it is a snapshot of
 std::mutex g_prepared_mutex;
 std::unordered_map<const void*, PreparedInfo> g_prepared;
 
 // null: not usable (with *err set when the caller passed a buffer that does not fit the call)
-const void* usable_prepared(const void* prepared, int kind, int Np, int nf, int Nfp, int flags, const char* what,
-                            int* err) {
+const void* usable_prepared(const void* prepared, const void* op, int kind, int Np, int nf, int Nfp, int flags,
+                            const char* what, int* err) {
     *err = FE_OK;
     if (!prepared) return nullptr;
     PreparedInfo info;
@@ -710,6 +749,13 @@ const void* usable_prepared(const void* prepared, int kind, int Np, int nf, int 
         *err = fail(FE_EINVAL, "%s: the prepared operator is for another call (kind %d Np %d nf %d Nfp %d flags %d; "
                     "this call: kind %d Np %d nf %d Nfp %d flags %d)", what, info.kind, info.Np, info.nf, info.Nfp,
                     info.flags, kind, Np, nf, Nfp, flags);
+        return nullptr;
+    }
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (info.op != op || info.device != dev) {   // a snapshot of ANOTHER operator array of the same shape would compute silently with it
+        *err = fail(FE_EINVAL, "%s: the prepared operator %p is a snapshot of the operator array %p on device %d, this call "
+                    "passes the operator array %p on device %d", what, prepared, info.op, info.device, op, dev);
         return nullptr;
     }
     return prepared;
@@ -798,7 +844,8 @@ int fe_prepare_operator(int32_t family, const double* op, int32_t Np, int32_t nf
     if ((reinterpret_cast<uintptr_t>(op) & 7u) || (reinterpret_cast<uintptr_t>(prepared) & 15u))
         return fail(FE_EINVAL, "prepare: the operator must be 8-byte and the prepared buffer 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    PreparedInfo info{0, Np, 0, 0, flags};
+    PreparedInfo info{0, Np, 0, 0, flags, op, -1};
+    (void)hipGetDevice(&info.device);
     if (family == FE_FAMILY_GRAD || family == FE_FAMILY_DIV || family == FE_FAMILY_GRADDIV) {
         if (flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "prepare: bad operator flags %d", flags);
         const int opT = (flags & FE_OP_TRANSPOSED) ? 1 : 0;
@@ -829,6 +876,44 @@ int fe_prepare_operator(int32_t family, const double* op, int32_t Np, int32_t nf
     std::lock_guard<std::mutex> lock(g_prepared_mutex);
     g_prepared[prepared] = info;
     return FE_OK;
+}
+
+int fe_release_prepared(const void* prepared) {
+    std::lock_guard<std::mutex> lock(g_prepared_mutex);
+    return g_prepared.erase(prepared) ? FE_OK : fail(FE_EINVAL, "fe_release_prepared: %p is not a prepared-operator buffer of this process", prepared);
+}
+
+int fe_split_alloc(void** ptr, size_t bytes, int32_t flags) {
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->alloc(ptr, bytes, flags);
+}
+
+int fe_split_free(void* ptr) {
+    if (!ptr) return FE_OK;
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->free_array(ptr);
+}
+
+int fe_split_info(const void* ptr, char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(FE_EINVAL, "fe_split_info: no buffer");
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->info(ptr, buf, buf_len);
+}
+
+int fe_split_stats(char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return fail(FE_EINVAL, "fe_split_stats: no buffer");
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->stats(buf, buf_len);
+}
+
+int fe_split_trim(void) {
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->trim();
 }
 
 int fe_kernel_resources(char* buf, size_t buf_len) {
@@ -881,7 +966,7 @@ int fe_grad3d_prepared_f64(const double* J, const double* D, const void* D_prepa
                                       op_flags, variant, stream);
     }
     int perr;
-    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, op_flags, "grad", &perr);
+    const void* prep = usable_prepared(D_prepared, D, kPreparedD, Np, 0, 0, op_flags, "grad", &perr);
     if (perr != FE_OK) return perr;
     for (int k = 0; k < b; ++k)
         if (int rc = check_common(J, D, u[k], out[k], E, Np)) return rc;
@@ -992,7 +1077,7 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
                                      op_flags, variant, stream);
     }
     int perr;
-    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, op_flags, "div", &perr);
+    const void* prep = usable_prepared(D_prepared, D, kPreparedD, Np, 0, 0, op_flags, "div", &perr);
     if (perr != FE_OK) return perr;
     fe::FieldPtrs P = {};
     for (int k = 0; k < b; ++k) {
@@ -1229,7 +1314,7 @@ int fe_graddiv3d_prepared_f64(const double* J, const double* D, const void* D_pr
                               const double* v_div, double* grad_out, double* div_out, int64_t E, int32_t Np,
                               int32_t variant, void* stream) {
     int perr;
-    const void* prep = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, 0, "graddiv", &perr);
+    const void* prep = usable_prepared(D_prepared, D, kPreparedD, Np, 0, 0, 0, "graddiv", &perr);
     if (perr != FE_OK) return perr;
     if (int rc = check_common(J, D, u_grad, grad_out, E, Np)) return rc;
     if (int rc = check_common(J, D, v_div, div_out, E, Np)) return rc;
@@ -1275,7 +1360,7 @@ int fe_facemass_prepared_f64(const double* J, const double* R, const void* R_pre
                              double* const* out, int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b,
                              int32_t layout_flags, int32_t variant, void* stream) {
     int perr;   // (the J layout flag is not part of the operator)
-    const void* prep = usable_prepared(R_prepared, kPreparedR, Np, nf, Nfp, layout_flags & ~FE_FM_J_FE, "face-mass", &perr);
+    const void* prep = usable_prepared(R_prepared, R, kPreparedR, Np, nf, Nfp, layout_flags & ~FE_FM_J_FE, "face-mass", &perr);
     if (perr != FE_OK) return perr;
     if (E < 0) return fail(FE_EINVAL, "E must be >= 0 (got %lld)", (long long)E);
     if (Np <= 0 || nf <= 0 || Nfp <= 0 || b <= 0)
@@ -1394,9 +1479,9 @@ int fe_waveop3d_prepared_f64(const double* J, const double* D, const void* D_pre
                              int64_t E, int32_t Np, int32_t nf, int32_t Nfp, int32_t b, int32_t fm_layout_flags,
                              int32_t variant, void* stream) {
     int perr;
-    const void* prepD = usable_prepared(D_prepared, kPreparedD, Np, 0, 0, 0, "waveop", &perr);
+    const void* prepD = usable_prepared(D_prepared, D, kPreparedD, Np, 0, 0, 0, "waveop", &perr);
     if (perr != FE_OK) return perr;
-    const void* prepR = usable_prepared(R_prepared, kPreparedR, Np, nf, Nfp, fm_layout_flags & ~FE_FM_J_FE, "waveop", &perr);
+    const void* prepR = usable_prepared(R_prepared, R, kPreparedR, Np, nf, Nfp, fm_layout_flags & ~FE_FM_J_FE, "waveop", &perr);
     if (perr != FE_OK) return perr;
     FmChoice geo{0, 16};
     const bool fused = (variant == FE_VARIANT_AUTO || variant == FE_VARIANT_MFMA) && nf == fe::kFmNf && Np != 56 &&

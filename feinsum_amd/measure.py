@@ -24,11 +24,12 @@ Argument conventions kept from the reference:
                (``"mfma"``, ``"generic"``, ``{"variant": "generic"}``) selects
                a variant explicitly; in a dict, ``"prepared": True`` lets a
                bound launch (``timeit``) use a prepared copy of its operator
-               matrices; ``"placement"`` (or ``$FEINSUM_PLACEMENT``): the default
-               ``"separate"`` times one allocation per array, as the reference
-               does; ``"tuned"`` is opt-in and makes ``timeit`` place its arrays
-               where the launch runs fastest (``feinsum_amd.placement``);
-               ``timeit_details(...).placement`` reports which was used.
+               matrices; ``"placement"`` (or ``$FEINSUM_PLACEMENT``): ``timeit``
+               allocates one array per operand as the reference does; with the
+               default ``"split"`` the outputs come from the split allocator
+               (``feinsum_amd.placement.zeros``), ``"separate"`` takes every array
+               from torch, ``"tuned"`` (opt-in) scans an arena for the fastest
+               position; ``timeit_details(...).placement`` reports which was used.
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -179,8 +180,10 @@ def result_dtype(einsum: BatchedEinsum, row: int = 0) -> np.dtype:
     return np.result_type(*[arg.dtype for arg in einsum.args[row]])
 
 
-def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int) -> Mapping[str, Any]:
-    """Zero-filled device outputs ``_fe_out, _fe_out_0, ...`` (reference: measure.py:44-60)."""
+def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int, *, split: bool = False) -> Mapping[str, Any]:
+    """Zero-filled device outputs ``_fe_out, _fe_out_0, ...`` (reference: measure.py:44-60).  *split*: one array each
+    from the split allocator (``feinsum_amd.placement.zeros``: halves in different classes of physical memory) instead
+    of the torch allocator; arrays too small to split come from torch either way."""
     import torch
 
     q = _as_queue(cq)
@@ -188,7 +191,12 @@ def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int) ->
     outs = {}
     for k, name in enumerate(einsum.output_names):
         tdtype = getattr(torch, result_dtype(einsum, k).name)
-        outs[name] = torch.zeros(shape, dtype=tdtype, device=q.torch_device)
+        if split:
+            from feinsum_amd import placement
+
+            outs[name] = placement.zeros(shape, tdtype, q.torch_device)
+        else:
+            outs[name] = torch.zeros(shape, dtype=tdtype, device=q.torch_device)
     return MappingProxyType(outs)
 
 
@@ -267,6 +275,15 @@ class _FamilyLaunch:
             pack.b, pack.layout_flags, pack.variant = k2 - k, plan.layout_flags, self.variant
             self.groups.append(pack)
             k = k2
+
+    def __del__(self) -> None:
+        # the library keeps a record per prepared buffer (address -> shape, source operator): drop it before the buffer
+        # is freed, or an unrelated later allocation at the same address would be taken for a prepared operator
+        for buf in getattr(self, "_prepared", {}).values():
+            try:
+                _hip.release_prepared(buf.data_ptr())
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def prepare_operators(self, stream_ptr: int = 0) -> int:
         """Write the operator of every launch group that has a prepared form (grad / div / face-mass of
@@ -537,23 +554,31 @@ def validate_batched_einsum_transform(einsum: BatchedEinsum, cq: Any, transform:
     logger.info("Statistically verified the soundness of the transformation")
 
 
-PLACEMENT_MODES = ("separate", "tuned")
+PLACEMENT_MODES = ("split", "separate", "tuned")
 
 
 def _placement_mode(transform: Any) -> str:
     """
-    Where ``timeit`` puts its arrays: ``transform={"placement": ...}``, else ``$FEINSUM_PLACEMENT``, else
-    ``"separate"`` -- one allocation per array, the reference's protocol (``src/feinsum/measure.py:44-60,80-108``)
-    and what a caller of :func:`evaluate` gets on arrays of its own.  ``"tuned"`` is opt-in: the arrays are carved out
-    of one large arena at the position where the launch times fastest (``feinsum_amd/placement.py``, DESIGN.md
-    section 3d); the number it yields holds for arrays placed that way only, and the :class:`TimingResult` says so.
+    Where ``timeit`` puts the arrays it allocates: ``transform={"placement": ...}``, else ``$FEINSUM_PLACEMENT``, else
+    ``"split"``.
+
+    ``"split"``     one allocation per array, as the reference does (``src/feinsum/measure.py:44-60,80-108``); the
+                    OUTPUTS come from the split allocator (``feinsum_amd.placement.zeros``), whose arrays have their
+                    halves in different classes of physical memory -- no arena, no scan, memory = the footprint, and a
+                    caller gets the same arrays for ``evaluate`` with ``placement.empty``.  Arrays below 256 MiB (the
+                    reference's default ``long_dim_length`` = 1e5) are ordinary torch allocations.
+    ``"separate"``  every array from the torch allocator: the reference's protocol to the letter, and what a caller
+                    who allocates with ``torch.empty`` gets.
+    ``"tuned"``     opt-in (round 2): all arrays in one large arena at the position where the launch times fastest
+                    (``placement.tune_base``); its number holds for arrays placed that way only.
+    The :class:`TimingResult` says which one was used (``record_facts`` stores it with the fact).
     """
     import os
 
     mode = transform.get("placement") if isinstance(transform, Mapping) else None
-    mode = mode or os.environ.get("FEINSUM_PLACEMENT") or "separate"
-    if mode == "auto":          # round 2's default; kept as a synonym of the reference-faithful mode
-        mode = "separate"
+    mode = mode or os.environ.get("FEINSUM_PLACEMENT") or "split"
+    if mode == "auto":          # round 2's default name
+        mode = "split"
     if mode not in PLACEMENT_MODES:
         raise InvalidParameterError(f"placement must be one of {PLACEMENT_MODES}, got {mode!r}")
     return mode
@@ -566,9 +591,10 @@ class TimingResult:
     seconds_device: float     # HIP-event time per launch (what timeit returns)
     seconds_wall: float       # host wall-clock per launch, reference protocol
     rounds: int
-    #: how the timed arrays were placed: {"mode": "separate"} (one allocation per array, the reference's protocol) or
-    #: the report of placement.tune_base_retry ({"mode": "tuned", arena size, positions scanned, whether a class
-    #: boundary was found, ...}); a tuned placement that could not be had says so under "fallback"
+    #: how the timed arrays were placed: {"mode": "split", "outputs": the allocator's report per output} (one allocation
+    #: per array, outputs from the split allocator), {"mode": "separate"} (every array from torch) or the report of
+    #: placement.tune_base_retry ({"mode": "tuned", arena size, positions scanned, whether a class boundary was found,
+    #: ...}); a placement that could not be had says so under "fallback"
     placement: Mapping[str, Any] = field(default_factory=lambda: MappingProxyType({"mode": "separate"}))
 
 
@@ -584,12 +610,27 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
     if validate:
         validate_batched_einsum_transform(einsum, q, transform, schedule)
     arg_dict = generate_input_arrays(q, einsum, long_dim_length)
-    out_dict = generate_out_arrays(q, einsum, long_dim_length)
+    mode = _placement_mode(transform)
+    report: Mapping[str, Any] = {"mode": "separate"}
+    if mode == "split":
+        from feinsum_amd import placement
+
+        try:
+            with torch.cuda.device(q.torch_device):
+                out_dict = generate_out_arrays(q, einsum, long_dim_length, split=True)
+            infos = {n: placement.split_info(t) for n, t in out_dict.items()}
+            report = {"mode": "split", "outputs": {n: (i.get("classes") or "torch allocation (below 256 MiB)") for n, i in infos.items()},
+                      "alloc_ms": round(sum(i.get("alloc_ms", 0.0) for i in infos.values()), 3)}
+        except (RuntimeError, HipLibraryError) as exc:     # the allocator could not serve: the reference's protocol, and say so
+            logger.warning("split allocator not available (%s); timing torch allocations", str(exc)[:160])
+            out_dict = generate_out_arrays(q, einsum, long_dim_length)
+            report = {"mode": "separate", "fallback": f"split allocator failed: {str(exc)[:160]}"}
+    else:
+        out_dict = generate_out_arrays(q, einsum, long_dim_length)
     # `transform={"prepared": True}`: the operator matrices are written once in fragment layout (see
     # _FamilyLaunch.prepare_operators) instead of being rebuilt by every launch
     prepare = _prepared_from_transform(transform, False)
-    report: Mapping[str, Any] = {"mode": "separate"}
-    if _placement_mode(transform) == "tuned":
+    if mode == "tuned":
         # the same arrays, moved into one arena at the position where the launch runs fastest (placement.py)
         from feinsum_amd import placement
 

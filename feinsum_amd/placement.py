@@ -27,6 +27,112 @@ from __future__ import annotations
 from typing import Any, Callable, Dict, List, Sequence, Tuple
 
 MIB = 1 << 20
+
+
+# --------------------------------------------------------------------------
+# the split allocator (round 3): arrays whose halves lie in different classes
+# of physical memory -- no arena, no timing scan (include/feinsum_hip.h,
+# feinsum_amd/csrc/fe_split_alloc.h)
+# --------------------------------------------------------------------------
+
+class _SplitBuffer:
+    """Owner of one ``fe_split_alloc`` array; torch reads it through ``__cuda_array_interface__`` and keeps this
+    object alive for as long as any tensor (or view) of the array lives; the memory returns to the pool with it."""
+
+    def __init__(self, nbytes: int, device_index: int) -> None:
+        from feinsum_amd import _hip
+
+        self.ptr, self.nbytes, self.device_index = _hip.split_alloc(nbytes), int(nbytes), int(device_index)
+        self._free = _hip.split_free     # (bound now: module globals may be gone at interpreter exit)
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (self.ptr, False),
+                                         "version": 3, "strides": None}
+
+    def __del__(self) -> None:
+        ptr, self.ptr = getattr(self, "ptr", 0), 0
+        if not ptr:
+            return
+        try:
+            import torch
+
+            with torch.cuda.device(self.device_index):
+                self._free(ptr)          # waits for the device like hipFree, then unmaps
+        except Exception:                # noqa: BLE001  (interpreter shutdown: the process is going away anyway)
+            pass
+
+
+def empty(shape: Sequence[int], dtype: Any = None, device: Any = None, *, written: bool = True) -> Any:
+    """
+    A new uninitialised device tensor, as ``torch.empty`` -- for arrays a launch WRITES taken from the split allocator:
+    the first half of the array is backed by physical memory of one class and the second half by another, and
+    successive calls alternate which class comes first.  Write streams split over two classes are what makes the DG
+    launches run at 77-79 % of the HBM roofline instead of 66-72 %: grad's three output planes
+    are split 2 + 1, the four face-mass outputs (allocated one after the other) 2 + 2, and div's single output is cut
+    in the middle for the two-window walk (``transform="mfma_split"``).  No arena and no timing scan: the memory mapped
+    is the array's size rounded up to 2 MiB; arrays below 256 MiB, ``written=False`` and CPU devices get a plain
+    ``torch.empty`` (where a read-only array lies does not matter).  The tensor is an ordinary torch tensor (views,
+    copies, kernels); its memory returns to the allocator's pool when the last view is gone.
+    """
+    import torch
+
+    dtype = dtype or torch.float64
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    shape = tuple(int(d) for d in shape)
+    nbytes = int(torch.Size(shape).numel()) * torch.empty((), dtype=dtype).element_size()
+    if not written or dev.type != "cuda" or nbytes < SPLIT_MIN_BYTES:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        buf = _SplitBuffer(nbytes, dev.index)
+        flat = torch.as_tensor(buf, device=dev)
+    if flat.data_ptr() != buf.ptr:
+        raise RuntimeError("torch copied the split allocator's array instead of wrapping it")
+    return flat.view(dtype).view(shape)
+
+
+def zeros(shape: Sequence[int], dtype: Any = None, device: Any = None, *, written: bool = True) -> Any:
+    """:func:`empty`, zero-filled (what the reference's ``cla.zeros`` outputs are: ``src/feinsum/measure.py:44-60``)."""
+    return empty(shape, dtype, device, written=written).zero_()
+
+
+#: below two pieces of 128 MiB there is nothing to split (include/feinsum_hip.h)
+SPLIT_MIN_BYTES = 256 * MIB
+
+
+def split_info(tensor: Any) -> Dict[str, Any]:
+    """What the allocator did for *tensor* (an array of :func:`empty`): ``{"bytes", "mapped_bytes", "piece_mib",
+    "classes": one digit per 128 MiB piece, "alloc_ms"}``; ``{}`` for any other tensor."""
+    import torch
+
+    from feinsum_amd import _hip
+    from feinsum_amd.diagnostics import InvalidParameterError
+
+    try:
+        with torch.cuda.device(tensor.device):
+            return _hip.split_info(tensor.untyped_storage().data_ptr())
+    except (InvalidParameterError, RuntimeError):
+        return {}
+
+
+def split_stats(device: Any = None) -> Dict[str, Any]:
+    """The pool of the split allocator on *device*: classes seen, free pieces, pieces created, probes, spacers, ms."""
+    import torch
+
+    from feinsum_amd import _hip
+
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        return _hip.split_stats()
+
+
+def split_trim(device: Any = None) -> None:
+    """Release the allocator's free pieces on *device* to the driver."""
+    import torch
+
+    from feinsum_amd import _hip
+
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _hip.split_trim()
+
 ALIGN = 2 * MIB
 #: candidate gaps between consecutive arrays, MiB: plateaus of the measured landscapes are >= 100 MiB wide, but where
 #: they lie differs from process to process (it follows the physical pages behind the arena), so the search is dense

@@ -267,6 +267,8 @@ def record_facts(einsum: BatchedEinsum, cq: Any, variant: str = "mfma",
         # how the timed arrays were placed is part of the fact (transform_params is the reference's JSON column for
         # what parametrises a measurement): "separate" = one allocation per array, what evaluate() callers get
         params["placement"] = timing.placement.get("mode", "separate")
+        if timing.placement.get("fallback"):
+            params["placement_fallback"] = timing.placement["fallback"]
         if timing.placement.get("mode") == "tuned":
             params["placement_report"] = {k: timing.placement[k] for k in
                                           ("class_boundary_found", "arenas_tried", "scan_positions", "scan_median_ms", "best_ms")

@@ -259,6 +259,12 @@ int fe_facemass_f64(const double* J, const double* R,
 #define FE_PREPARED_OPERATOR_BYTES (96 * 1024)
 int fe_prepare_operator(int32_t family, const double* op, int32_t Np, int32_t nf, int32_t Nfp,
                         int32_t flags, void* prepared, void* stream);
+/* The record of a prepared buffer also holds the address of the operator array it is a snapshot of and the device:
+ * a *_prepared_* launch whose operator argument is another array (or that runs on another device) is refused with
+ * FE_EINVAL instead of silently computing with the snapshot.  Call fe_release_prepared BEFORE freeing a prepared buffer:
+ * it drops the record, so that an unrelated later allocation at the same address is not taken for a prepared operator
+ * (FE_EINVAL if `prepared` has no record). */
+int fe_release_prepared(const void* prepared);
 
 /* fe_grad3d_batched_f64 / fe_div3d_batched_f64 / fe_facemass_f64 / fe_graddiv3d_f64 /
  * fe_waveop3d_f64 with the operator(s) ALSO given in prepared form (or NULL). */
@@ -293,6 +299,33 @@ int fe_waveop3d_prepared_f64(const double* J, const double* D, const void* D_pre
  * launch on a device.)  Returns the full length of the table; at most buf_len - 1 characters are
  * copied.  No reference counterpart: the reference reads such figures off loopy's generated code. */
 int fe_kernel_resources(char* buf, size_t buf_len);
+
+/* ---- split allocator: arrays whose halves lie in different classes of physical memory ------------------------
+ * New functionality; it replaces the per-array allocation of the reference's timing path (cla.zeros / cl.array.to_device
+ * through a PyOpenCL MemoryPool, src/feinsum/measure.py:44-60,80-108,236-246) for arrays a launch WRITES.
+ * On MI355X write streams confined to one class of physical memory are ~25 % slower than streams split over two
+ * (DESIGN.md section 3d); the DG launches gain 8-14 % when their concurrently written planes / arrays are split.
+ * fe_split_alloc returns a virtually contiguous device array of `bytes` bytes on the current device whose first half
+ * is backed by physical memory of one class and whose second half by another (128 MiB pieces, each classified by a
+ * two-stream write probe when the pool first obtains it; successive allocations alternate which class comes first).
+ * No timing scan, no arena: mapped memory = bytes rounded up to 2 MiB.  Arrays below 256 MiB are one plain handle.
+ * Address ranges are never re-used within a process (ROCm 7.2 keeps translating a re-mapped range to its first handle:
+ * tools/vmm_remap_test.cpp); a freed array gives its memory back, not its (plentiful) address space.
+ * The pointer is an ordinary device pointer for kernels, copies and the launchers of this library; it must be released
+ * with fe_split_free (not hipFree), which waits for the device like hipFree does and returns the pieces to the pool.
+ * Synchronous host calls, serialised per device; `flags` is reserved (0).
+ *   fe_split_info   JSON about one array: {"bytes", "mapped_bytes", "piece_mib", "classes": one digit per piece
+ *                   (class id in order of discovery, 't' = the unclassified tail piece), "alloc_ms"}
+ *   fe_split_stats  JSON about the current device's pool: classes seen, free pieces per class, pieces created, probes,
+ *                   spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_arrays" counts arrays that
+ *                   had to take both halves from one class (no second class found within the budget)
+ *   fe_split_trim   releases the pool's free pieces to the driver
+ * Both JSON calls return the length written (>= 0) or a negative error code. */
+int fe_split_alloc(void** ptr, size_t bytes, int32_t flags);
+int fe_split_free(void* ptr);
+int fe_split_info(const void* ptr, char* buf, size_t buf_len);
+int fe_split_stats(char* buf, size_t buf_len);
+int fe_split_trim(void);
 
 /* Algorithmic flops per element for a family (numerator of GFLOP/s; same
  * counter as measure.py:278-331 on the opt_einsum-optimal schedule):

@@ -222,8 +222,8 @@ def test_record_facts_measures_and_retrieve_picks_the_faster_variant(tmp_path):
     facts = {q.transform_id: q for q in f.query(expr, f.DeviceQueue(0).device, database=db)}
     assert facts["mfma"].runtime_in_sec < facts["generic"].runtime_in_sec
     best = f.retrieve(expr, f.DeviceQueue(0).device, database=db)
-    assert dict(best) == {"variant": "mfma", "placement": "separate"}     # the fact says how its arrays were placed
-    assert facts["mfma"].transform_params == {"placement": "separate"}
+    assert dict(best) == {"variant": "mfma", "placement": "split"}        # the fact says how its arrays were placed
+    assert facts["mfma"].transform_params == {"placement": "split"}
     assert f.timeit(expr, cq=0, transform=best, long_dim_length=20_000) > 0
 
 

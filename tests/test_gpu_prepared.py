@@ -123,6 +123,10 @@ def test_buffers_that_do_not_fit_the_call_are_refused():
     torch.cuda.synchronize()
     with pytest.raises(InvalidParameterError, match="another call"):
         grad(buf.data_ptr(), flags=1)                        # prepared for the untransposed layout
+    # a snapshot of ANOTHER operator array of the same shape and flags is refused too (it would compute with that one)
+    D_other = D.clone()
+    with pytest.raises(InvalidParameterError, match="snapshot of the operator array"):
+        _hip.check(lib.fe_grad3d_prepared_f64(J.data_ptr(), D_other.data_ptr(), buf.data_ptr(), up, op_, E, Np, 1, 0, 0, 0))
     with pytest.raises(InvalidParameterError, match="another call"):      # a D buffer is not an R buffer
         v = torch.zeros((4, E, 15), dtype=torch.float64, device="cuda")
         o = torch.zeros((E, Np), dtype=torch.float64, device="cuda")
@@ -145,5 +149,43 @@ def test_timeit_options_prepared_and_tuned_placement():
     for t in (t_plain, t_prep, t_tuned):
         assert 0 < t.seconds_device < 1e-3
     # the result says how its arrays were placed (a recorded fact must be reproducible by a caller)
-    assert t_plain.placement["mode"] == "separate" and t_prep.placement["mode"] == "separate"
+    assert t_plain.placement["mode"] == "split" and t_prep.placement["mode"] == "split"
+    t_sep = measure.timeit_details(expr, cq=0, long_dim_length=100_000, min_secs=0.2, transform={"placement": "separate"})
+    assert t_sep.placement["mode"] == "separate" and 0 < t_sep.seconds_device < 1e-3
     assert t_tuned.placement["mode"] == "tuned" and "class_boundary_found" in t_tuned.placement
+
+
+def test_release_drops_the_record_of_a_prepared_buffer():
+    """fe_release_prepared: afterwards the address is no prepared operator any more (a later unrelated allocation at the
+    same address must not be taken for one: ADVICE r02); bound launches release their buffers when they go away."""
+    import gc
+
+    import torch
+
+    from feinsum_amd.diagnostics import InvalidParameterError
+
+    E, Np = 64, 35
+    host = generate_host_input_arrays(dg.grad(), E)
+    J, D, u = (torch.from_numpy(host[k]).cuda() for k in ("J", "R", "u"))
+    out = torch.empty((3, E, Np), dtype=torch.float64, device="cuda")
+    lib = _hip.load_library()
+    buf = torch.empty(_hip.PREPARED_OPERATOR_BYTES, dtype=torch.uint8, device="cuda")
+    up, op_ = _hip._ptr_array([u.data_ptr()]), _hip._ptr_array([out.data_ptr()])
+    _hip.prepare_operator(1, D.data_ptr(), Np, 0, 0, 0, buf.data_ptr())
+    _hip.check(lib.fe_grad3d_prepared_f64(J.data_ptr(), D.data_ptr(), buf.data_ptr(), up, op_, E, Np, 1, 0, 0, 0))
+    torch.cuda.synchronize()
+    _hip.release_prepared(buf.data_ptr())
+    with pytest.raises(InvalidParameterError, match="not written by fe_prepare_operator"):
+        _hip.check(lib.fe_grad3d_prepared_f64(J.data_ptr(), D.data_ptr(), buf.data_ptr(), up, op_, E, Np, 1, 0, 0, 0))
+    with pytest.raises(InvalidParameterError):
+        _hip.release_prepared(buf.data_ptr())                # no record left
+    # a bound launch with prepared operators releases its records with itself
+    dev = _dev(torch, host)
+    op = f.bind_operator([(dg.grad(), dev)], 0, prepare=True)
+    ptrs = [b.data_ptr() for st in op._stages for b in st._prepared.values()]
+    assert ptrs
+    del op
+    gc.collect()
+    for ptr in ptrs:
+        with pytest.raises(InvalidParameterError):
+            _hip.release_prepared(ptr)

@@ -34,16 +34,17 @@ def test_split_order_puts_one_cut_through_every_stage():
 
 
 def test_placement_mode_of_timeit(monkeypatch):
-    """``timeit`` times one allocation per array unless asked otherwise (the reference's protocol is the
-    default; a tuned arena is opt-in through the transform or the environment)."""
+    """``timeit`` times one allocation per array (outputs from the split allocator) unless asked otherwise (ADVICE r02:
+    the tuned arena is opt-in through the transform or the environment)."""
     from feinsum_amd import measure
     from feinsum_amd.diagnostics import InvalidParameterError
 
     monkeypatch.delenv("FEINSUM_PLACEMENT", raising=False)
-    assert measure._placement_mode(None) == "separate" and measure._placement_mode("mfma") == "separate"
-    assert measure._placement_mode({"variant": "mfma"}) == "separate"
+    assert measure._placement_mode(None) == "split" and measure._placement_mode("mfma") == "split"
+    assert measure._placement_mode({"variant": "mfma"}) == "split"
     assert measure._placement_mode({"placement": "tuned"}) == "tuned"
-    assert measure._placement_mode({"placement": "auto"}) == "separate"       # round 2's default name
+    assert measure._placement_mode({"placement": "separate"}) == "separate"
+    assert measure._placement_mode({"placement": "auto"}) == "split"          # round 2's default name
     monkeypatch.setenv("FEINSUM_PLACEMENT", "tuned")
     assert measure._placement_mode(None) == "tuned"
     assert measure._placement_mode({"placement": "separate"}) == "separate"   # the transform wins over the environment
@@ -100,3 +101,87 @@ def test_tuned_layout_gives_the_same_results():
     make_step(views)(1)
     q.finish()
     assert torch.equal(views["_fe_out"], ref)
+
+
+@pytest.mark.gpu
+def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
+    """feinsum_amd.placement.empty: arrays of the split allocator (fe_split_alloc) behind torch tensors -- results of
+    launches that write into them are bitwise those of torch allocations; the allocator's report; memory comes back."""
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd import _hip
+
+    E = 1_000_000
+    before = placement.split_stats(0)
+    out = placement.empty((3, E, 35), torch.float64, "cuda:0")
+    assert out.shape == (3, E, 35) and out.dtype == torch.float64 and out.is_contiguous() and out.device.index == 0
+    info = placement.split_info(out)
+    assert info["bytes"] == 3 * E * 35 * 8 and info["bytes"] <= info["mapped_bytes"] < info["bytes"] + (2 << 20)
+    cls = info["classes"]
+    assert len(cls) == 7 and cls.endswith("t")                    # six pieces of 128 MiB and the tail
+    stats = placement.split_stats(0)
+    if stats["classes"] >= 2 and not stats["unsplit_arrays"]:     # (a device of one class has nothing to split)
+        assert len(set(cls[:3])) == 1 and len(set(cls[3:6])) == 1 and cls[0] != cls[3], cls
+    assert placement.split_info(out[1]) == info                   # views belong to the same array
+    assert placement.split_info(torch.empty(4, device="cuda:0")) == {}
+    # torch kernels and feinsum launches on the array
+    out.fill_(float("nan"))
+    expr = dg.grad()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dev = {"J": torch.rand((3, 3, E), dtype=torch.float64, device="cuda", generator=g),
+           "R": torch.rand((3, 35, 35), dtype=torch.float64, device="cuda", generator=g),
+           "u": torch.rand((E, 35), dtype=torch.float64, device="cuda", generator=g)}
+    ref = f.evaluate(expr, 0, dev, wait=True)["_fe_out"]
+    res = f.evaluate(expr, 0, dev, out_dict={"_fe_out": out}, wait=True)["_fe_out"]
+    assert res.data_ptr() == out.data_ptr() and torch.equal(res, ref)
+    assert float(out.sum()) == float(ref.sum())
+    # four face-mass outputs allocated one after the other: the orientation alternates
+    outs = [placement.zeros((E, 35), torch.float64, "cuda:0") for _ in range(4)]
+    infos = [placement.split_info(t)["classes"] for t in outs]
+    if stats["classes"] >= 2 and not placement.split_stats(0)["unsplit_arrays"]:
+        assert all(len(c) == 3 and c[0] != c[1] for c in infos), infos
+    fm = dg.face_mass(4)
+    fdev = {name: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in fm.arg_to_shape[name]),
+                             dtype=torch.float64, device="cuda", generator=g) for name in sorted(fm.all_args)}
+    fref = f.evaluate(fm, 0, fdev, wait=True)
+    fres = f.evaluate(fm, 0, fdev, out_dict=dict(zip(fm.output_names, outs)), wait=True)
+    for name in fm.output_names:
+        assert torch.equal(fres[name], fref[name])
+    # small arrays, read-only arrays and CPU arrays are plain torch allocations
+    assert placement.split_info(placement.empty((1000, 35), torch.float64, "cuda:0")) == {}
+    assert placement.split_info(placement.empty((3, E, 35), torch.float64, "cuda:0", written=False)) == {}
+    assert placement.empty((10, 3), torch.float32, "cpu").device.type == "cpu"
+    # the memory returns to the pool with the last view
+    live = placement.split_stats(0)["live_arrays"]
+    view = out[2]
+    del out, res
+    assert placement.split_stats(0)["live_arrays"] == live        # the view keeps the array
+    del view
+    assert placement.split_stats(0)["live_arrays"] == live - 1
+    del outs, fres
+    after = placement.split_stats(0)
+    assert after["live_arrays"] == before["live_arrays"] and after["live_bytes"] == before["live_bytes"]
+    with pytest.raises(f.InvalidParameterError):
+        _hip.split_free(12345 * 4096)                             # not an array of the allocator
+
+
+@pytest.mark.gpu
+def test_split_allocator_never_hands_out_an_address_twice():
+    """ROCm 7.2 keeps translating a re-mapped virtual range to its FIRST physical handle (tools/vmm_remap_test.cpp), so
+    the allocator must never re-use an address: allocate / free cycles return distinct pointers, and what is written
+    through a new array is what is read back after the pool has recycled the physical pieces."""
+    import torch
+
+    seen = set()
+    for cycle in range(6):
+        t = placement.empty((40_000_000,), torch.float64, "cuda:0")          # 320 MB: two pieces and a tail
+        assert t.data_ptr() not in seen
+        seen.add(t.data_ptr())
+        t.fill_(float(cycle + 1))
+        u = placement.empty((40_000_000,), torch.float64, "cuda:0")
+        u.fill_(-float(cycle + 1))
+        assert float(t[0]) == cycle + 1 and float(t[-1]) == cycle + 1 and float(t.sum()) == (cycle + 1) * 40_000_000.0
+        assert float(u[0]) == -(cycle + 1) and float(u[-1]) == -(cycle + 1)
+        del t, u

@@ -124,8 +124,30 @@ struct Set {
         other.resize(h.size());
         printf("# %s against the reference (x 0.1 ms; o = other superclass):", what);
         for (size_t i = 0; i < h.size(); ++i) {
-            t[i] = wprobe_ms(ref, at((int)i));
+            t[i] = wprobe_ms(ref, at((int)i) == ref ? ref + 128 * MIB : at((int)i));
             other[i] = t[i] < t_other + 0.3 * (t_same - t_other);
+            printf(" %.3f%c", t[i] * 10, other[i] ? 'o' : ' ');
+        }
+        printf("\n");
+    }
+    // grow the set (one handle every 2 GiB of allocation order) until `need` handles of either kind are present
+    void create_until(size_t bytes, size_t stride_, int need, int max_n, char* ref, double t_same, double t_other, const char* what) {
+        size = bytes;
+        stride = stride_;
+        CK(hipMemAddressReserve((void**)&va, stride * max_n, 2 * MIB, nullptr, 0));
+        int have[2] = {0, 0};
+        printf("# %s against the reference (x 0.1 ms; o = other superclass):", what);
+        while ((int)h.size() < max_n && (have[0] < need || have[1] < need)) {
+            const int i = (int)h.size();
+            hipMemGenericAllocationHandle_t hh, sp;
+            CK(hipMemCreate(&hh, size, &prop, 0));
+            CK(hipMemMap(va + stride * i, size, 0, hh, 0));
+            CK(hipMemSetAccess(va + stride * i, size, &acc, 1));
+            CK(hipMemCreate(&sp, 2 * GIB - size, &prop, 0));
+            h.push_back(hh);
+            t.push_back(wprobe_ms(ref, at(i)));
+            other.push_back(t[i] < t_other + 0.3 * (t_same - t_other));
+            ++have[other[i]];
             printf(" %.3f%c", t[i] * 10, other[i] ? 'o' : ' ');
         }
         printf("\n");
@@ -175,19 +197,19 @@ int main() {
 
     // ---- 2 GiB handles, as tools/vmm_class_probe.cpp
     Set B;
-    B.create(24, 2 * GIB, 2 * GIB, 0);
+    B.create(16, 2 * GIB, 2 * GIB, 0);
     char* ref = B.at(0);
     double t_same = wprobe_ms(ref, B.at(0, 128 * MIB)), t_other = t_same;
-    for (int i = 1; i < 24; ++i) t_other = std::min(t_other, wprobe_ms(ref, B.at(i)));
+    for (int i = 1; i < 16; ++i) t_other = std::min(t_other, wprobe_ms(ref, B.at(i)));
     printf("# write probe 2 x 128 MiB: same region %.4f ms, fastest pair %.4f ms\n", t_same, t_other);
-    if (t_same / t_other < 1.1) { printf("# no second class among 24 handles of 2 GiB\n"); return 0; }
+    if (t_same / t_other < 1.1) { printf("# no second class among 16 handles of 2 GiB\n"); return 0; }
     B.classify(ref, t_same, t_other, "2 GiB handles (first 128 MiB)");
     {   // the second GiB of every handle (address bit 30?)
         printf("# second GiB of the 2 GiB handles against the reference:");
-        for (int i = 0; i < 24; ++i) printf(" %.3f", wprobe_ms(ref, B.at(i, GIB)) * 10);
+        for (int i = 0; i < 16; ++i) printf(" %.3f", wprobe_ms(ref, B.at(i, GIB)) * 10);
         printf("\n");
     }
-    const int Y = B.find(1), X2 = B.find(0, 1);
+    const int Y = B.find(1), X2 = B.find(0, 1);   // (handle 0 itself is 'same' by construction)
     if (Y < 0) { printf("# no handle of another superclass\n"); return 0; }
     printf("# X = handle 0, Y = handle %d (other superclass), X2 = handle %d (same superclass as X)\n", Y, X2);
     for (int rep = 0; rep < 2; ++rep) {
@@ -204,18 +226,24 @@ int main() {
 
     // ---- smaller handles, each at a virtual address of its own (1 GiB apart), never re-mapped
     Set H1, H2, H4;
-    H1.create(12, GIB, GIB, GIB);                 // 1 GiB handles, one every 2 GiB of allocation order
-    H1.classify(ref, t_same, t_other, "1 GiB handles");
-    H2.create(16, 2 * W, GIB, GIB);               // 536 MiB
-    H2.classify(ref, t_same, t_other, "536 MiB handles");
-    H4.create(24, W, GIB, GIB);                   // 268 MiB
-    H4.classify(ref, t_same, t_other, "268 MiB handles");
+    H1.create_until(GIB, GIB, 2, 30, ref, t_same, t_other, "1 GiB handles");
+    H2.create_until(2 * W, GIB, 2, 30, ref, t_same, t_other, "536 MiB handles");
+    H4.create_until(W, GIB, 2, 30, ref, t_same, t_other, "268 MiB handles");
     for (int rep = 0; rep < 2; ++rep) {
         {
-            const int p = H1.find(0), q = H1.find(1), p2 = H1.find(0, 1);
+            const int p = H1.find(0), q = H1.find(1), p2 = H1.find(0, 1), q2 = H1.find(1, 1);
             if (p >= 0 && q >= 0) fm("1 GiB handles: P+0, P+W, Q+0, Q+W  (P same superclass as X, Q other)", H1.at(p), H1.at(p, W), H1.at(q), H1.at(q, W));
             if (p >= 0 && p2 >= 0) fm("1 GiB handles: P+0, P+W, P2+0, P2+W  (both of X's superclass)", H1.at(p), H1.at(p, W), H1.at(p2), H1.at(p2, W));
             if (q >= 0) fm("mixed: X+0, X+W (2 GiB handle), Q+0, Q+W (1 GiB handle of the other superclass)", B.at(0), B.at(0, W), H1.at(q), H1.at(q, W));
+            if (p >= 0 && p2 >= 0 && q >= 0 && q2 >= 0) {
+                fm("1 GiB handles, one output each, all at offset 0: P, P2, Q, Q2", H1.at(p), H1.at(p2), H1.at(q), H1.at(q2));
+                fm("1 GiB handles, one output each, offsets 0, W, 2W, 3W - 1 GiB wrap: P, P2+W, Q+2W, Q2+512MiB", H1.at(p), H1.at(p2, W), H1.at(q, 2 * W),
+                   H1.at(q2, 512 * MIB));
+                fm("1 GiB handles, one output each, offsets 0, 33 MiB, 66 MiB, 99 MiB: P, P2, Q, Q2", H1.at(p), H1.at(p2, 33 * MIB), H1.at(q, 66 * MIB),
+                   H1.at(q2, 99 * MIB));
+                fm("1 GiB handles, one output each, offsets 0, 1 MiB, 2 MiB, 3 MiB: P, P2, Q, Q2", H1.at(p), H1.at(p2, 1 * MIB), H1.at(q, 2 * MIB),
+                   H1.at(q2, 3 * MIB));
+            }
         }
         {
             const int p = H2.find(0), q = H2.find(1), p2 = H2.find(0, 1);
@@ -230,6 +258,7 @@ int main() {
                 fm("268 MiB handles at their own addresses: P, Q, P2, Q2", H4.at(p), H4.at(q), H4.at(p2), H4.at(q2));
             }
             if (q >= 0 && q2 >= 0) fm("mixed: X+0, X+W (2 GiB handle), Q, Q2 (268 MiB handles of the other superclass)", B.at(0), B.at(0, W), H4.at(q), H4.at(q2));
+            if (q >= 0 && q2 >= 0) fm("mixed: X+0, X+33MiB+W (2 GiB handle), Q, Q2 (268 MiB handles of the other superclass)", B.at(0), B.at(0, W + 33 * MIB), H4.at(q), H4.at(q2));
             if (p >= 0 && p2 >= 0) fm("mixed: Y+0, Y+W (2 GiB handle), P, P2 (268 MiB handles of X's superclass)", B.at(Y), B.at(Y, W), H4.at(p), H4.at(p2));
         }
     }

@@ -287,9 +287,12 @@ int main(int argc, char** argv) {
         patterns.push_back({nm, [k](int pl, int q) { return ((q / k) + pl) & 1; }});
     }
     const int ppl = (int)(W / P);                          // pieces per 268 MiB plane slot
-    char* ov;                                               // 4 plane slots of W bytes
-    CK(hipMemAddressReserve((void**)&ov, 4 * W, 2 * MIB, nullptr, 0));
+    // EVERY composition gets an address range that was never mapped before: on this stack a range that is unmapped and
+    // mapped again keeps translating to its first handles (tools/vmm_remap_test.cpp), which is why the first version of
+    // this phase timed every pattern alike (profiles/r03/vmm_interleave_probe_run2.txt)
+    char* ov = nullptr;                                     // 4 plane slots of W bytes
     auto compose = [&](int nplanes, bool contiguous_planes, const std::function<int(int, int)>& f) {
+        CK(hipMemAddressReserve((void**)&ov, 4 * W, 2 * MIB, nullptr, 0));   // never freed
         // contiguous_planes (grad): one array [3][E][Np], plane x starts at byte x * plane (not piece aligned)
         size_t used[2] = {0, 0};
         const int npieces = contiguous_planes ? (int)((nplanes * plane + P - 1) / P) : nplanes * ppl;
