@@ -474,7 +474,7 @@ def main() -> None:
                          "MFMA fragments in every launch; measured: no gain, see DESIGN.md")
     ap.add_argument("--placement", default="split", choices=["split", "separate", "tuned"],
                     help="split (default): one allocation per array, the OUTPUTS from the split allocator "
-                         "(feinsum_amd.placement.zeros: halves in different classes of physical memory; no arena, no scan); "
+                         "(feinsum_amd.placement.zeros: 4 MiB pieces alternating between two classes of physical memory; no arena, no scan); "
                          "separate: every array from torch; tuned (round 2): all arrays in one large arena, at the "
                          "position that times fastest")
     ap.add_argument("--arena-gib", type=float, default=66.0, help="size of the placement arena (tuned placement)")
@@ -596,15 +596,15 @@ def main() -> None:
         pool = placement.split_stats(device)
         placement_report = {
             "mode": "split",
-            "what": "one allocation per array; outputs from the split allocator (fe_split_alloc: 128 MiB pieces classified by a "
-                    "two-stream write probe, first half of an array in one class of physical memory, second half in another; "
-                    "no arena, no timing scan)",
-            "output_piece_classes": [i.get("classes", "torch allocation (below 256 MiB)") for i in infos],
+            "what": "one allocation per array; outputs from the split allocator (fe_split_alloc: 4 MiB pieces alternating between "
+                    "two classes of physical memory, classified in groups of 128 MiB by a two-stream write probe; no arena, no "
+                    "timing scan)",
+            "output_pieces_by_class": [i.get("pieces_by_class", "torch allocation (below 8 MiB)") for i in infos],
             "output_bytes": sum(int(t.numel()) * t.element_size() for od in out_dicts for t in od.values()),
             "output_mapped_bytes": sum(i.get("mapped_bytes", 0) for i in infos),
             "allocator_ms": round(pool["setup_ms"] + pool["alloc_ms_total"], 3),
             "inputs_and_outputs_ready_ms": round(t_alloc, 1),
-            "pool": {k: pool[k] for k in ("classes", "pieces_created", "probes", "spacers_created", "spacer_bytes_peak",
+            "pool": {k: pool[k] for k in ("classes", "pieces_created", "groups_probed", "probes", "probe_ms", "spacers_created", "spacer_bytes_peak", "spacer_ms", "groups_discarded",
                                             "unsplit_arrays", "pooled_bytes", "walk_gave_up")},
         }
     else:

@@ -182,8 +182,8 @@ def result_dtype(einsum: BatchedEinsum, row: int = 0) -> np.dtype:
 
 def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int, *, split: bool = False) -> Mapping[str, Any]:
     """Zero-filled device outputs ``_fe_out, _fe_out_0, ...`` (reference: measure.py:44-60).  *split*: one array each
-    from the split allocator (``feinsum_amd.placement.zeros``: halves in different classes of physical memory) instead
-    of the torch allocator; arrays too small to split come from torch either way."""
+    from the split allocator (``feinsum_amd.placement.zeros``: 4 MiB pieces alternating between two classes of physical
+    memory) instead of the torch allocator; arrays below 8 MiB come from torch either way."""
     import torch
 
     q = _as_queue(cq)
@@ -563,10 +563,9 @@ def _placement_mode(transform: Any) -> str:
     ``"split"``.
 
     ``"split"``     one allocation per array, as the reference does (``src/feinsum/measure.py:44-60,80-108``); the
-                    OUTPUTS come from the split allocator (``feinsum_amd.placement.zeros``), whose arrays have their
-                    halves in different classes of physical memory -- no arena, no scan, memory = the footprint, and a
-                    caller gets the same arrays for ``evaluate`` with ``placement.empty``.  Arrays below 256 MiB (the
-                    reference's default ``long_dim_length`` = 1e5) are ordinary torch allocations.
+                    OUTPUTS come from the split allocator (``feinsum_amd.placement.zeros``), whose arrays alternate
+                    between two classes of physical memory every 4 MiB -- no arena, no scan, memory = the footprint, and
+                    a caller gets the same arrays for ``evaluate`` with ``placement.empty``.
     ``"separate"``  every array from the torch allocator: the reference's protocol to the letter, and what a caller
                     who allocates with ``torch.empty`` gets.
     ``"tuned"``     opt-in (round 2): all arrays in one large arena at the position where the launch times fastest
@@ -619,7 +618,8 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
             with torch.cuda.device(q.torch_device):
                 out_dict = generate_out_arrays(q, einsum, long_dim_length, split=True)
             infos = {n: placement.split_info(t) for n, t in out_dict.items()}
-            report = {"mode": "split", "outputs": {n: (i.get("classes") or "torch allocation (below 256 MiB)") for n, i in infos.items()},
+            report = {"mode": "split", "outputs": {n: ({"pieces_by_class": i["pieces_by_class"], "first_pieces": i["first_pieces"]} if i
+                                                      else "torch allocation (below 8 MiB)") for n, i in infos.items()},
                       "alloc_ms": round(sum(i.get("alloc_ms", 0.0) for i in infos.values()), 3)}
         except (RuntimeError, HipLibraryError) as exc:     # the allocator could not serve: the reference's protocol, and say so
             logger.warning("split allocator not available (%s); timing torch allocations", str(exc)[:160])

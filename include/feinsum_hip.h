@@ -300,25 +300,26 @@ int fe_waveop3d_prepared_f64(const double* J, const double* D, const void* D_pre
  * copied.  No reference counterpart: the reference reads such figures off loopy's generated code. */
 int fe_kernel_resources(char* buf, size_t buf_len);
 
-/* ---- split allocator: arrays whose halves lie in different classes of physical memory ------------------------
+/* ---- split allocator: arrays backed by ALTERNATING pieces of two classes of physical memory -------------------
  * New functionality; it replaces the per-array allocation of the reference's timing path (cla.zeros / cl.array.to_device
  * through a PyOpenCL MemoryPool, src/feinsum/measure.py:44-60,80-108,236-246) for arrays a launch WRITES.
  * On MI355X write streams confined to one class of physical memory are ~25 % slower than streams split over two
- * (DESIGN.md section 3d); the DG launches gain 8-14 % when their concurrently written planes / arrays are split.
- * fe_split_alloc returns a virtually contiguous device array of `bytes` bytes on the current device whose first half
- * is backed by physical memory of one class and whose second half by another (128 MiB pieces, each classified by a
- * two-stream write probe when the pool first obtains it; successive allocations alternate which class comes first).
- * No timing scan, no arena: mapped memory = bytes rounded up to 2 MiB.  Arrays below 256 MiB are one plain handle.
+ * (DESIGN.md section 3d); the DG launches gain 5-14 % when every stream's write window is spread over two classes.
+ * fe_split_alloc returns a virtually contiguous device array of `bytes` bytes on the current device whose 4 MiB pieces
+ * (one physical handle each) alternate between two classes; the class of memory is measured when the pool obtains it
+ * (groups of 32 pieces, a two-stream write probe against a reference group of every class seen so far).
+ * No timing scan, no arena: mapped memory = bytes rounded up to 2 MiB.  Arrays below 8 MiB are one plain handle.
  * Address ranges are never re-used within a process (ROCm 7.2 keeps translating a re-mapped range to its first handle:
  * tools/vmm_remap_test.cpp); a freed array gives its memory back, not its (plentiful) address space.
  * The pointer is an ordinary device pointer for kernels, copies and the launchers of this library; it must be released
  * with fe_split_free (not hipFree), which waits for the device like hipFree does and returns the pieces to the pool.
  * Synchronous host calls, serialised per device; `flags` is reserved (0).
- *   fe_split_info   JSON about one array: {"bytes", "mapped_bytes", "piece_mib", "classes": one digit per piece
- *                   (class id in order of discovery, 't' = the unclassified tail piece), "alloc_ms"}
- *   fe_split_stats  JSON about the current device's pool: classes seen, free pieces per class, pieces created, probes,
- *                   spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_arrays" counts arrays that
- *                   had to take both halves from one class (no second class found within the budget)
+ *   fe_split_info   JSON about one array: {"bytes", "mapped_bytes", "piece_mib", "pieces", "pieces_by_class" (class ids
+ *                   in order of discovery), "first_pieces": the classes of the first 16 pieces, "tail_bytes": the last,
+ *                   unclassified handle, "alloc_ms"}
+ *   fe_split_stats  JSON about the current device's pool: classes seen, free pieces per class, pieces created, groups
+ *                   probed, spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_arrays" counts
+ *                   arrays that had to take all pieces from one class (no second class found within the budget)
  *   fe_split_trim   releases the pool's free pieces to the driver
  * Both JSON calls return the length written (>= 0) or a negative error code. */
 int fe_split_alloc(void** ptr, size_t bytes, int32_t flags);

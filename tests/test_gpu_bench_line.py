@@ -71,7 +71,11 @@ def test_bench_default_and_tuned_placements(workload, placement):
     assert line["config"]["variant"] == "auto"                   # no silent switch of the kernel variant
     if placement == "split":
         rep = line["placement"]
-        assert len(rep["output_piece_classes"]) == (1 if workload == "grad" else 4)
+        assert len(rep["output_pieces_by_class"]) == (1 if workload == "grad" else 4)
+        if rep["pool"]["classes"] >= 2 and not rep["pool"]["unsplit_arrays"]:      # alternating pieces: two classes, equal shares
+            for counts in rep["output_pieces_by_class"]:
+                used = sorted(c for c in counts if c)
+                assert len(used) == 2 and used[1] - used[0] <= 1, counts
         assert rep["output_bytes"] <= rep["output_mapped_bytes"] < rep["output_bytes"] + 4 * (2 << 20)
         assert rep["allocator_ms"] < 5000 and "scan_positions" not in rep
 

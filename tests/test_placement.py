@@ -119,11 +119,15 @@ def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
     assert out.shape == (3, E, 35) and out.dtype == torch.float64 and out.is_contiguous() and out.device.index == 0
     info = placement.split_info(out)
     assert info["bytes"] == 3 * E * 35 * 8 and info["bytes"] <= info["mapped_bytes"] < info["bytes"] + (2 << 20)
-    cls = info["classes"]
-    assert len(cls) == 7 and cls.endswith("t")                    # six pieces of 128 MiB and the tail
+    n = 3 * E * 35 * 8 // (4 << 20)
+    assert info["piece_mib"] == 4 and info["pieces"] == n and sum(info["pieces_by_class"]) == n
+    assert info["tail_bytes"] == info["mapped_bytes"] - n * (4 << 20)
     stats = placement.split_stats(0)
-    if stats["classes"] >= 2 and not stats["unsplit_arrays"]:     # (a device of one class has nothing to split)
-        assert len(set(cls[:3])) == 1 and len(set(cls[3:6])) == 1 and cls[0] != cls[3], cls
+    if stats["classes"] >= 2 and not stats["unsplit_arrays"]:     # (a device of one class has nothing to alternate)
+        used = sorted(c for c in info["pieces_by_class"] if c)
+        assert len(used) == 2 and used[1] - used[0] <= 1, info      # two classes, equal shares ...
+        head = info["first_pieces"]
+        assert len(head) == 16 and all(head[k] != head[k + 1] for k in range(15)), head   # ... alternating piece by piece
     assert placement.split_info(out[1]) == info                   # views belong to the same array
     assert placement.split_info(torch.empty(4, device="cuda:0")) == {}
     # torch kernels and feinsum launches on the array
@@ -139,9 +143,10 @@ def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
     assert float(out.sum()) == float(ref.sum())
     # four face-mass outputs allocated one after the other: the orientation alternates
     outs = [placement.zeros((E, 35), torch.float64, "cuda:0") for _ in range(4)]
-    infos = [placement.split_info(t)["classes"] for t in outs]
+    infos = [placement.split_info(t) for t in outs]
+    assert all(i["pieces"] == E * 35 * 8 // (4 << 20) for i in infos)
     if stats["classes"] >= 2 and not placement.split_stats(0)["unsplit_arrays"]:
-        assert all(len(c) == 3 and c[0] != c[1] for c in infos), infos
+        assert all(i["first_pieces"][0] != i["first_pieces"][1] for i in infos), [i["first_pieces"] for i in infos]
     fm = dg.face_mass(4)
     fdev = {name: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in fm.arg_to_shape[name]),
                              dtype=torch.float64, device="cuda", generator=g) for name in sorted(fm.all_args)}
@@ -176,7 +181,7 @@ def test_split_allocator_never_hands_out_an_address_twice():
 
     seen = set()
     for cycle in range(6):
-        t = placement.empty((40_000_000,), torch.float64, "cuda:0")          # 320 MB: two pieces and a tail
+        t = placement.empty((40_000_000,), torch.float64, "cuda:0")          # 320 MB: 76 pieces and a tail
         assert t.data_ptr() not in seen
         seen.add(t.data_ptr())
         t.fill_(float(cycle + 1))

@@ -71,7 +71,8 @@ def main() -> None:
 
     rec = {"workload": workload, "E": E, "kernel": kernel, "source_sha": bench.kernel_source_sha(),
            "profile": "rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python3 bench.py "
-                      f"--workload {workload} --no-cpu-baseline --no-protocol --steps 10 --warmup 2 (tools/profile_round.sh)",
+                      f"--workload {workload} --no-cpu-baseline --no-protocol --setup-launches 3 --steps 10 --warmup 2, default placement "
+                      "(outputs from the split allocator; tools/profile_round.sh)",
            "dispatches_per_pass": ndisp[kernel], "counters": c}
     if mean("FETCH_SIZE") is not None:
         rec["hbm_read_bytes_per_launch"] = 2.0 * mean("FETCH_SIZE") * 1024.0

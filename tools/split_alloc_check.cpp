@@ -84,7 +84,7 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static void show_info(const char* what, const void* p) {
-    char buf[2048];
+    char buf[4096];
     FE(fe_split_info(p, buf, sizeof buf));
     printf("  %-14s %s\n", what, buf);
 }
