@@ -63,7 +63,9 @@ def main() -> None:
             ndisp[k] = len(v)
     if not dur_sum:
         raise SystemExit("no counter_collection.csv found")
-    kernel = max(dur_sum, key=dur_sum.get)
+    # the workload's kernel: the library's own (fe::...), not the allocator's classification probe and not torch's fills
+    ours = {k: v for k, v in dur_sum.items() if "fe::" in k and "split_probe_kernel" not in k} or dur_sum
+    kernel = max(ours, key=ours.get)
     c = merged[kernel]
     mean = lambda name: c[name]["mean"] if name in c else None   # noqa: E731
 

@@ -20,9 +20,10 @@ for w in $workloads; do
   echo "== $w: kernel trace"
   # --no-protocol: no 2 s reference-protocol loop and no A/B launch on torch allocations in the profiled process, so that
   # every dispatch of the workload's kernel is the SAME bound launch on the SAME (split allocator) arrays: the average of
-  # <w>_kernel_stats.csv is the timed kernel alone (round 2's average mixed in ~200 positions of an arena scan)
+  # <w>_kernel_stats.csv is the timed kernel alone (round 2's average mixed in ~200 positions of an arena scan); 3000 timed
+  # steps so that the 120 setup / warm-up launches (first touch, clocks ramping: up to 280 us) weigh < 1 % in the average
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$w" -o $w -- python3 "$repo/bench.py" --workload $w --no-cpu-baseline \
-      --no-protocol > "$out/bench_${w}_under_rocprof.json" 2> "$out/$w.err" || { tail -5 "$out/$w.err"; exit 1; }
+      --no-protocol --steps 3000 > "$out/bench_${w}_under_rocprof.json" 2> "$out/$w.err" || { tail -5 "$out/$w.err"; exit 1; }
   cp "$out/bench_${w}_under_rocprof.json" "$keep/"
   f=$(find "$out/$w" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$keep/${w}_kernel_stats.csv"
   n=0
