@@ -14,8 +14,9 @@ default; ``--elems-total`` splits one global batch instead); the only exchange
 is the all-gather of the per-shard result reductions, after the timed region.
 Rank 0 prints ONE JSON line.
 
-Measurement protocol: ``setup_launches`` untimed launches (first touch of every
-page, kernel attributes, device clocks settled -- reported in the line), W
+Measurement protocol: ``setup_launches`` untimed launches over ``setup_seconds``
+(first touch of every page, kernel attributes, device clocks and power state
+settled -- both reported in the line), W
 untimed warm-up steps, barrier + synchronize, K timed steps enqueued back to
 back on the launch stream and bracketed by HIP events on that same stream
 (fe_time_launches of the C ABI), barrier + synchronize; the step time is the
@@ -42,7 +43,8 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 NP, NF, NFP, NFIELDS = 35, 4, 15, 4
-SETUP_LAUNCHES = 100           # untimed, before the W warm-up steps; reported as `setup_launches`
+SETUP_LAUNCHES = 100           # untimed, before the W warm-up steps; reported as `setup_launches` ...
+SETUP_SECONDS = 0.5            # ... and continued until this much time has passed (`setup_seconds`): see main()
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_GFLOPS = 78_600.0    # fp64 vector = matrix
 WORKLOADS = ("grad", "div", "facemass", "graddiv", "pipeline")
@@ -467,6 +469,9 @@ def main() -> None:
     ap.add_argument("--cpu-baseline", default="bounded", choices=["bounded", "full"],
                     help="full: the complete reference timing protocol for the E = 1e6 stand-ins too (~2-3 min)")
     ap.add_argument("--no-protocol", action="store_true", help="skip the reference-protocol timing (2 s)")
+    ap.add_argument("--setup-seconds", type=float, default=SETUP_SECONDS,
+                    help="untimed launches continue until this many seconds have passed (reported in the line): the device's "
+                         "memory clocks and power state settle over the first ~0.3 s of load")
     ap.add_argument("--setup-launches", type=int, default=SETUP_LAUNCHES,
                     help="untimed launches before the warm-up steps (reported in the line)")
     ap.add_argument("--prepare", action="store_true",
@@ -614,12 +619,20 @@ def main() -> None:
     prepared = any(getattr(b, "_prepared", None) for b in op._stages)
 
     s = q.stream_ptr
-    # setup, untimed and not counted as warm-up steps (SETUP_LAUNCHES is reported in the line): kernel
-    # attributes, first touch of every page, device clocks settled -- a 5-step run right after
-    # allocation measured 12 % low otherwise
-    for _ in range(args.setup_launches):
-        op.launch(s)
-    sync()
+    # setup, untimed and not counted as warm-up steps (both figures are reported in the line): kernel attributes, first
+    # touch of every page, device clocks and power state settled.  At least `--setup-launches` launches and at least
+    # `--setup-seconds` of them: 105 launches (21 ms of work) into a fresh process the same bound launch still ran 3-4 %
+    # slower than in the 2 s reference-protocol loop behind the timed region (0.1969-0.2010 against 0.1936-0.1943 ms in
+    # four runs, 11 % at E = 1e5: profiles/r03/bench_grad_driver_style_short_setup.txt); round 2's arena scan had hidden
+    # that behind its ~2000 launches
+    t_setup = time.perf_counter()
+    setup_launches = 0
+    while setup_launches < args.setup_launches or time.perf_counter() - t_setup < args.setup_seconds:
+        for _ in range(50):
+            op.launch(s)
+        setup_launches += 50
+        sync()
+    setup_seconds = time.perf_counter() - t_setup
     for _ in range(args.warmup):
         op.launch(s)
 
@@ -694,7 +707,8 @@ def main() -> None:
         flops_all = float(t.item())
 
     if info.rank == 0:
-        extra = {"result_reduction_ms": round(reduction_ms, 3), "result_allgather_ms": round(allgather_ms, 3),
+        extra = {"setup_seconds": round(setup_seconds, 3),
+                 "result_reduction_ms": round(reduction_ms, 3), "result_allgather_ms": round(allgather_ms, 3),
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
@@ -712,7 +726,7 @@ def main() -> None:
                                  "host_ms_per_step": round(protocol_ms["host"], 5)}
             extra["device_under_load"] = device_under_load
         line = compose_line(workload=args.workload, n_gpus=info.world_size, steps=args.steps, warmup=args.warmup,
-                            setup_launches=args.setup_launches,
+                            setup_launches=setup_launches,
                             wall_s=wall_s, kernel_s=kernel_s, flops_step_all=flops_all, flops_step_rank0=flops_step,
                             bytes_step_rank0=bytes_step, elems_rank0=E, elems_total=args.elems_total,
                             variant=variant, device_name=q.device.name, entry_points=op.entry_points,

@@ -80,8 +80,12 @@ constexpr int kSplitProbePasses = 2;                // the probe writes 2 stream
 // a first version that made a 6.4 TB/s group the anchor of a "new class" then read every later group as unlike it and
 // gave up (profiles/r03/split_alloc_check_v7_weak_anchors.txt).  $FEINSUM_SPLIT_SAME_BELOW_GBPS /
 // $FEINSUM_SPLIT_OTHER_ABOVE_GBPS override the bounds.
-constexpr double kSplitSameBelowGBps = 6150.0;
-constexpr double kSplitOtherAboveGBps = 6500.0;
+// A group is accepted for a class only on a CONSISTENT reading: like that class's reference (below the first bound) and
+// unlike every other known reference (above the second).  A group that is half one class and half another reads ~6.0
+// against both -- accepted on the first test alone it diluted its class, and the launches ran at 73-75 % instead of 77 %
+// in about one process of three (profiles/r03/bench_*_v11_*.json).
+constexpr double kSplitSameBelowGBps = 5950.0;
+constexpr double kSplitOtherAboveGBps = 6400.0;
 constexpr size_t kSplitSpacerUnit = 32 * kSplitMiB;   // see acquire()
 constexpr size_t kSplitAnchorBytes = 256 * kSplitMiB; // a class's reference region: ONE handle (one buddy block: pure)
 constexpr int kSplitMaxClasses = 3;                 // three superclasses on MI355X (a fourth "class" would be a misreading)
@@ -396,6 +400,16 @@ class SplitPool {
             last_probes_ += note;
             if (rate < slowest_rate) { slowest_rate = rate; slowest = c; }
             if (rate < same_below_gbps_) { cls = c; break; }
+        }
+        if (cls >= 0) {   // like reference `cls`: it must also be unlike all the others (else: a mixture)
+            for (int c = 0; c < (int)anchors_.size() && cls >= 0; ++c) {
+                if (c == cls) continue;
+                double rate;
+                if (int rc = probe_gbps(anchors_[c], at, &rate)) return rc;
+                snprintf(note, sizeof note, "%d:%.0f ", c, rate);
+                last_probes_ += note;
+                if (rate < other_above_gbps_) { cls = -1; slowest_rate = 0.0; }   // (0: not a candidate for a new class either)
+            }
         }
         if (cls < 0 && slowest_rate >= other_above_gbps_ && (int)anchors_.size() < kSplitMaxClasses) {
             // clearly unlike every reference region: a class not seen before.  Its reference region is a fresh 256 MiB handle

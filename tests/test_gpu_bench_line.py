@@ -13,7 +13,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-SMALL = ["--steps", "3", "--warmup", "1", "--setup-launches", "5", "--elems-per-gpu", "20000", "--no-cpu-baseline",
+SMALL = ["--steps", "3", "--warmup", "1", "--setup-launches", "5", "--setup-seconds", "0", "--elems-per-gpu", "20000", "--no-cpu-baseline",
          "--no-protocol", "--placement", "separate"]
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "setup_launches"}

@@ -1,6 +1,7 @@
-"""MFMA kernels of all tetrahedral orders: one torch allocation per array against the tuned placement.
+"""MFMA kernels of all tetrahedral orders: every array from torch ("separate") against outputs from the split allocator
+("split", timeit's default; pass "tuned" as a second argument to add round 2's arena scan).
 
-    python tools/bench_orders_placement.py [E]
+    python tools/bench_orders_placement.py [E] [tuned]
 """
 import sys
 
@@ -17,7 +18,8 @@ for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
         gops = f.count_ops(expr, long_dim_length=E) * 1e-9
         roof = f.get_roofline_flop_rate(expr, "AMD Instinct MI355X", E)[np.dtype("float64")]
         row = []
-        for what, tr in (("separate", {"variant": "mfma", "placement": "separate"}), ("tuned", {"variant": "mfma", "placement": "tuned"})):
+        modes = ["separate", "split"] + (["tuned"] if "tuned" in sys.argv[2:] else [])
+        for what, tr in ((m, {"variant": "mfma", "placement": m}) for m in modes):
             r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
             row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")
         print(f"Np = {Np:2d} {name:14s} " + " | ".join(row), flush=True)

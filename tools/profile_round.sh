@@ -31,7 +31,7 @@ for w in $workloads; do
     n=$((n+1))
     echo "== $w: pmc pass $n ($group)"
     rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$out/pmc_${w}_$n" -o pmc -- python3 "$repo/bench.py" --workload $w \
-        --no-cpu-baseline --no-protocol --setup-launches 3 --steps 10 --warmup 2 > /dev/null 2> "$out/pmc_${w}_$n.err" \
+        --no-cpu-baseline --no-protocol --setup-launches 3 --setup-seconds 0 --steps 10 --warmup 2 > /dev/null 2> "$out/pmc_${w}_$n.err" \
         || { tail -5 "$out/pmc_${w}_$n.err"; exit 1; }
   done
   E=1000000
