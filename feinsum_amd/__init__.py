@@ -19,7 +19,8 @@ from feinsum_amd.einsum import (Array, BatchedEinsum, EinsumAxisAccess, FreeAxis
 from feinsum_amd.family import KernelPlan, match_family
 from feinsum_amd.make_einsum import array, batched_einsum, einsum
 from feinsum_amd.canonicalization import canonicalize_einsum
-from feinsum_amd.sql_utils import QueryInfo, get_timed_einsums_in_db, query, record_facts, retrieve
+from feinsum_amd.sql_utils import (QueryInfo, get_timed_einsums_in_db, query, query_reference_archive, record_facts,
+                                   retrieve)
 from feinsum_amd.operator import BoundOperator, bind_operator, evaluate_operator
 from feinsum_amd.measure import (DeviceQueue, evaluate, generate_input_arrays, generate_out_arrays,
                                  get_roofline_flop_rate, measure_giga_op_rate,
@@ -33,7 +34,7 @@ __all__ = (
     "TransformValidationError", "array", "batched_einsum", "bind_operator", "canonicalize_einsum", "count_ops", "einsum", "evaluate", "evaluate_operator",
     "generate_input_arrays", "generate_out_arrays", "get_opt_einsum_contraction_schedule",
     "get_roofline_flop_rate", "get_timed_einsums_in_db", "get_trivial_contraction_schedule", "match_family",
-    "measure_giga_op_rate", "query", "record_facts", "retrieve", "stringify_comparison_vs_roofline", "timeit", "timeit_details",
+    "measure_giga_op_rate", "query", "query_reference_archive", "record_facts", "retrieve", "stringify_comparison_vs_roofline", "timeit", "timeit_details",
     "validate_batched_einsum_transform",
 )
 

@@ -154,13 +154,13 @@ __device__ __forceinline__ void stage_operator_dma(const double* __restrict__ g,
 // after the first wave of an XCD), with no LDS staging and no barrier.
 // The buffer has a fixed size (kPreparedBytes), so a kernel reading its own section can never run
 // past the allocation even when handed a buffer prepared for another shape.
-constexpr int kPrepHeaderBytes = 256;                 // magic, family, Np, nf, Nfp, flags
+constexpr int kPrepHeaderBytes = 256;                 // reserved, not written: what a buffer holds is recorded on the HOST
+                                                      // (feinsum_hip.hip: g_prepared -- shape, flags, source operator, device)
 constexpr int kPrepGradOff = kPrepHeaderBytes;        // grad section: <= 64 fragments (Np = 35: 63)
 constexpr int kPrepDivOff = kPrepGradOff + 32 * 1024; // div section: big-tile fragments, then the 4-row groups
 constexpr int kPrepDivSmallOff = kPrepDivOff + 32 * 1024;
 constexpr int kPrepFmOff = kPrepHeaderBytes;          // face-mass buffers hold R: big tiles, then 4-row groups
 constexpr int kPreparedBytes = 96 * 1024;
-constexpr unsigned long long kPrepMagic = 0x6665707265703031ull;   // "feprep01"
 
 // `count` fragments of this lane from a prepared section; set(f, value) receives them.  Plain loads:
 // the caller makes the compiler's own wait explicit (prepared_fragments_landed) before its main loop.

@@ -16,6 +16,14 @@
 
 namespace fe {
 
+// The grad section of a prepared D buffer -- formed only in the prepared instantiations (no arithmetic on a null pointer
+// in the plain ones, whose `prep` argument is null).
+template <bool kPrep>
+__device__ __forceinline__ const void* prepared_grad_section(const void* prep) {
+    if constexpr (kPrep) return reinterpret_cast<const char*>(prep) + kPrepGradOff;
+    else return nullptr;
+}
+
 // between two bodies: nothing of the finished body may still be in flight towards LDS, and
 // every wave of the block must be done with its private buffers before the next body stages
 // its operator over them
@@ -49,10 +57,10 @@ __global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
     if (!swap) {
         div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x);
         body_boundary();
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, reinterpret_cast<const char*>(prep) + kPrepGradOff, 1, 3, E,
+        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
                                                  nTilesG, op, blockIdx.x, gridDim.x);
     } else {
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, reinterpret_cast<const char*>(prep) + kPrepGradOff, 1, 3, E,
+        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
                                                  nTilesG, op, blockIdx.x, gridDim.x);
         body_boundary();
         div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x);
@@ -87,10 +95,10 @@ __global__ __launch_bounds__(256, 2) void waveop3d_mfma_kernel(WaveOpArgs a, Gra
         div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
                                                               gridDim.x);
         body_boundary();
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, reinterpret_cast<const char*>(a.prepD) + kPrepGradOff, 1, 3, a.E,
+        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
                                                  a.nTilesG, 0, blockIdx.x, gridDim.x);
     } else {
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, reinterpret_cast<const char*>(a.prepD) + kPrepGradOff, 1, 3, a.E,
+        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
                                                  a.nTilesG, 0, blockIdx.x, gridDim.x);
         body_boundary();
         div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,

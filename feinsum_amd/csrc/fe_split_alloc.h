@@ -137,6 +137,7 @@ class SplitPool {
         if (const char* thr = getenv("FEINSUM_SPLIT_SAME_BELOW_GBPS")) same_below_gbps_ = atof(thr);
         if (const char* thr = getenv("FEINSUM_SPLIT_OTHER_ABOVE_GBPS")) other_above_gbps_ = atof(thr);
         if (const char* gib = getenv("FEINSUM_SPLIT_SEARCH_GIB")) search_budget_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
+        if (const char* ms = getenv("FEINSUM_SPLIT_SEARCH_MS")) search_ms_budget_ = atof(ms);
         // the anchor of class 0: ONE handle of 256 MiB (a single block of the driver's allocator, hence of one class --
         // a group of 32 small handles may straddle two runs, and an impure anchor makes every later reading ambiguous:
         // profiles/r03/split_alloc_check_v10_group_anchors_impure.txt); it stays mapped for the life of the process
@@ -286,6 +287,7 @@ class SplitPool {
     double spacer_ms_ = 0, probe_ms_ = 0;
     size_t search_budget_ = 96ull << 30;   // how far a search for another class may skip ahead ($FEINSUM_SPLIT_SEARCH_GIB)
     size_t groups_discarded_ = 0;
+    double search_ms_budget_ = 4000.0;     // ... and how long the skipping itself may take ($FEINSUM_SPLIT_SEARCH_MS)
     std::vector<hipMemGenericAllocationHandle_t> discarded_;   // pieces of ambiguous groups: held while a search runs
     size_t pieces_created_ = 0, groups_probed_ = 0, probes_ = 0, spacer_bytes_peak_ = 0, spacers_created_ = 0, unsplit_arrays_ = 0;
     size_t live_bytes_ = 0, va_reserved_ = 0;
@@ -496,11 +498,13 @@ class SplitPool {
         const size_t max_new = walk_gave_up_ ? 2 * need_groups + 2 : 8 * need_groups + 64;   // groups obtained in this call at most
         size_t made = 0, run = 0;
         int rc = FE_OK;
+        const double spacer_ms_at_start = spacer_ms_;
         while (!pick(ca, cb) && made < max_new) {
             // the driver hands out long runs of one class: with enough of the current run's class in the pool, skip
             // ahead with an unmapped spacer (doubling, 1 ... 16 GiB) before the next group
             if (free_[last_cls_].size() >= need && run >= 3) {
                 if (spacer_bytes >= spacer_budget) break;   // nowhere left to search
+                if (spacer_ms_ - spacer_ms_at_start > search_ms_budget_) break;   // the driver is clearing what is skipped: enough
                 if (spacer_bytes + next_spacer > spacer_budget) next_spacer = (spacer_budget - spacer_bytes) / kSplitGran * kSplitGran;
                 if (next_spacer == 0) break;
                 // The skipped memory is taken in handles of 32 MiB, not in one large handle: the driver's buddy allocator

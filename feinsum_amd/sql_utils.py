@@ -17,7 +17,14 @@ read a database written here; what differs is what the columns *mean*:
 keys                  the einsum is keyed by the canonical form of
                       ``feinsum_amd.canonicalization`` (exhaustive search), not by the
                       reference's graph-canonical labelling: the two sets of keys do not
-                      collide and cannot be looked up from one another.
+                      collide.  Archives WRITTEN BY THE REFERENCE can still be read:
+                      :func:`query_reference_archive` re-canonicalises every key of such an
+                      archive (the shipped ``data/transform_archive_v2...v5.sqlite`` in
+                      their older ``use_matrix`` layout as well as the current layout of
+                      ``src/feinsum/sql_utils.py:389-415``) and returns the facts recorded
+                      for an einsum -- the reference's own timings, e.g. for a
+                      side-by-side table; their ``transform_id`` names a loopy transform
+                      file, which this backend cannot run.
 
 :func:`retrieve` closes the loop the reference closes with its archive: it returns the
 recorded variant with the highest GFLOP/s as a ``transform`` that ``timeit`` /
@@ -290,3 +297,72 @@ def record_facts(einsum: BatchedEinsum, cq: Any, variant: str = "mfma",
     finally:
         if own:
             conn.close()
+
+
+# -- reading archives written by the reference ------------------------------------------
+
+def _einsum_of_reference_key(subscripts: str, index_to_length: Mapping[str, int], names: Sequence[Sequence[Any]],
+                             dtypes: Mapping[str, str]) -> BatchedEinsum:
+    """A reference archive key as a BatchedEinsum.  *names*: the argument-name matrix, one row per batch member; an
+    entry is a name (current layout, ``args``) or a list of value names (older ``use_matrix`` layout: an array access
+    that multiplies several values becomes one operand per value with the same indices)."""
+    from feinsum_amd.make_einsum import array, batched_einsum
+
+    ins, out = subscripts.replace(" ", "").split("->")
+    in_sets = ins.split(",")
+    shape = lambda idxs: tuple(index_to_length.get(ch, ch.upper()) for ch in idxs)   # noqa: E731
+    as_list = lambda entry: list(entry) if isinstance(entry, (list, tuple)) else [entry]   # noqa: E731
+    subs = ",".join(s for s, uses in zip(in_sets, names[0]) for _ in as_list(uses)) + "->" + out
+    args = [[array(name, shape(s), dtypes[name]) for s, uses in zip(in_sets, row) for name in as_list(uses)] for row in names]
+    return batched_einsum(subs, args)
+
+
+def query_reference_archive(einsum: BatchedEinsum, database: Union[str, sqlite3.Connection], *,
+                            device_name: Optional[str] = None) -> Tuple[QueryInfo, ...]:
+    """
+    The facts an archive WRITTEN BY THE REFERENCE holds for *einsum* (any naming, any operand order): every distinct
+    key of the archive is rebuilt as a :class:`BatchedEinsum` and compared in this build's canonical form.  Reads the
+    shipped ``data/transform_archive_v2...v5.sqlite`` (one table per device in v2, columns ``use_matrix`` /
+    ``value_to_dtype``) and the current layout (``FEINSUM_TIMING_FACTS`` with ``args`` / ``arg_to_dtype``,
+    ``src/feinsum/sql_utils.py:389-415``).  *device_name*: keep only facts of that device (mangled as the reference
+    does, e.g. ``"NVIDIA_TITAN_V"``; for v2 the table name).  The returned ``QueryInfo.transform_id`` is the reference's
+    transform file; ``giga_op_rate`` works as for facts of this build.
+    """
+    want = _key(canonicalize_einsum(einsum))
+    conn, own = _connect(database)
+    hits = []
+    try:
+        tables = [name for (name,) in conn.execute("select name from sqlite_master where type='table'")
+                  if not name.startswith("sqlite_")]
+        for table in tables:
+            cols = [row[1] for row in conn.execute(f"pragma table_info({table})")]
+            if "subscripts" not in cols or "runtime_in_sec" not in cols:
+                continue
+            names_col = "args" if "args" in cols else "use_matrix"
+            dtype_col = "arg_to_dtype" if "arg_to_dtype" in cols else "value_to_dtype"
+            device_expr = "device_name" if "device_name" in cols else f"'{table}'"
+            params_expr = "transform_params" if "transform_params" in cols else "'{}'"
+            compiler_expr = "compiler_version" if "compiler_version" in cols else "''"
+            matching = {}
+            for subs, i2l, names, dts in conn.execute(
+                    f"select distinct subscripts, index_to_length, {names_col}, {dtype_col} from {table}"):
+                try:
+                    key = _key(canonicalize_einsum(_einsum_of_reference_key(subs, json.loads(i2l), json.loads(names),
+                                                                            json.loads(dts))))
+                except (ValueError, TypeError, NotImplementedError, AssertionError):
+                    continue        # a key this build's builders do not accept: not a match for anything it can evaluate
+                if key == want:
+                    matching[(subs, i2l, names, dts)] = True
+            for subs, i2l, names, dts in matching:
+                for tid, params, runtime, compiler, gops, dev in conn.execute(
+                        f"select transform_id, {params_expr}, runtime_in_sec, {compiler_expr}, giga_op_info, {device_expr} "
+                        f"from {table} where subscripts = ? and index_to_length = ? and {names_col} = ? and {dtype_col} = ?",
+                        (subs, i2l, names, dts)):
+                    if device_name is not None and dev != device_name:
+                        continue
+                    hits.append(QueryInfo(tid, load_transform_params(params), float(runtime), compiler or "",
+                                          load_op_info(gops), einsum))
+    finally:
+        if own:
+            conn.close()
+    return tuple(hits)

@@ -93,3 +93,30 @@ def test_shipped_archive_has_the_headline_facts():
     for expr in (dg.grad(), dg.div(), dg.face_mass(), dg.grad(56), dg.div(56), dg.face_mass(4, Np=56, Nfp=21), tri_grad,
                  dg.mass_apply(4), dg.cross_product_batch()):
         assert dict(sql_utils.retrieve(expr, dev))["variant"] == "mfma", expr.get_subscripts()
+
+
+def test_facts_of_the_reference_archives_can_be_read(golden_dir):
+    """`query_reference_archive`: the einsum keys of an archive written by the reference (bliss-canonical names, here in
+    the older `use_matrix` layout of data/transform_archive_v2...v5.sqlite) are re-canonicalised, so its facts are found
+    for any naming and operand order of the same einsum.  Fixture: rows extracted by
+    tests/golden/make_archive_sqlite_fixture.py (data the reference holds)."""
+    db = str(golden_dir / "ref_archive_extract.sqlite")
+    grad = sql_utils.query_reference_archive(dg.grad(), db, device_name="NVIDIA_TITAN_V")
+    assert grad and {q.transform_id for q in grad} == {"xre_rij_ej_to_xei.py", "batched_xre_rij_ej_to_xei.py"}   # (b = 1 keys too)
+    best = min(grad, key=lambda q: q.runtime_in_sec)
+    assert best.runtime_in_sec == pytest.approx(0.3985e-3, rel=2e-3)             # BASELINE.md: 2002 GFLOP/s on the TITAN V
+    assert best.giga_op_rate("float64") == pytest.approx(2002, rel=2e-3)
+    assert best.transform_params["n_e_per_wg"] == 21 and best.transform_params["nwork_items_per_e"] == 12
+    # the same einsum with other names and another operand order
+    other = f.einsum("pq,mnq,nqk->mpk", f.array("field", ("Nel", 35)), f.array("jac", (3, 3, "Nel")),
+                     f.array("diff", (3, 35, 35)))
+    renamed = sql_utils.query_reference_archive(other, db, device_name="NVIDIA_TITAN_V")
+    assert sorted(q.runtime_in_sec for q in renamed) == sorted(q.runtime_in_sec for q in grad)
+    div = sql_utils.query_reference_archive(dg.div(), db)
+    assert min(q.runtime_in_sec for q in div) == pytest.approx(0.4159e-3, rel=2e-3)
+    lift = sql_utils.query_reference_archive(dg.face_mass_ifj_fe(4), db)
+    assert min(q.runtime_in_sec for q in lift) == pytest.approx(0.7795e-3, rel=2e-3)
+    assert all(q.giga_op_info[np.dtype("float64")] == pytest.approx(1.704) for q in lift)
+    # an einsum the archive does not hold, and a device it has no facts for
+    assert sql_utils.query_reference_archive(dg.grad(20), db, device_name="AMD_Instinct_MI355X") == ()
+    assert sql_utils.query_reference_archive(f.einsum("ij,jk->ik", f.array("A", (7, 7)), f.array("B", (7, 7))), db) == ()
