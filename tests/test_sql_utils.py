@@ -108,7 +108,7 @@ def test_facts_of_the_reference_archives_can_be_read(golden_dir):
     assert best.giga_op_rate("float64") == pytest.approx(2002, rel=2e-3)
     assert best.transform_params["n_e_per_wg"] == 21 and best.transform_params["nwork_items_per_e"] == 12
     # the same einsum with other names and another operand order
-    other = f.einsum("pq,mnq,nqk->mpk", f.array("field", ("Nel", 35)), f.array("jac", (3, 3, "Nel")),
+    other = f.einsum("pq,mnp,nkq->mpk", f.array("field", ("Nel", 35)), f.array("jac", (3, 3, "Nel")),
                      f.array("diff", (3, 35, 35)))
     renamed = sql_utils.query_reference_archive(other, db, device_name="NVIDIA_TITAN_V")
     assert sorted(q.runtime_in_sec for q in renamed) == sorted(q.runtime_in_sec for q in grad)
