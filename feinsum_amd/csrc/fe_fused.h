@@ -54,6 +54,20 @@ __global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
     // body alive across the other and spills -- 408 bytes of scratch per lane and 4.7 % more HBM traffic, measured.)
     const bool swap = ((opT & 256) && blockIdx.x >= gridDim.x / 2) || ((opT & 512) && (blockIdx.x & 1));
     const int op = opT & 1;
+#ifdef FE_EXPERIMENTS
+    if ((opT & 1024) && gridDim.x >= 2 && (gridDim.x & 1) == 0) {
+        // ROLE SPLIT (bit 10; experiment build only -- measured in round 3 and 0.5 % slower): the older half of the grid runs div over ALL tiles,
+        // the younger half grad over all tiles, both in the same tile order -- block b and block b + half lie on the same
+        // XCD (blocks go round the eight XCDs), so the J tile the second of them asks for can still be in that XCD's L2
+        const unsigned half = gridDim.x / 2;
+        if (blockIdx.x < half)
+            div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, half);
+        else
+            grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E, nTilesG, op,
+                                                     blockIdx.x - half, half);
+        return;
+    }
+#endif
     if (!swap) {
         div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x);
         body_boundary();
