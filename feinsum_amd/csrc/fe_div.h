@@ -358,6 +358,51 @@ __device__ __forceinline__ void div3d_mfma_body(
         //      stores -- 0.390-0.398 ms against 0.375-0.386 for this loop: neither helps.  The per-wave chain
         //      load -> MFMAs -> three planes through the one buffer is what binds (p = 5).
         constexpr bool kTicket = (kDbg & 64) != 0, kEarly = (kDbg & 16) != 0;
+        // kRegPre (round 3): the NEXT unit's u tile and J rows are fetched into REGISTERS right after this unit's B values
+        // have left the buffer -- 14 + 4 doubles per lane, in flight during the 210 MFMAs -- and written into the (one)
+        // tile buffer after this unit's planes have gone out through it.  The LDS-DMA flavour can only ask for the next
+        // tile once that buffer is free, i.e. after the stores, and then waits at the top of the loop for the loads AND,
+        // through vmcnt(0), for those stores.
+        constexpr bool kRegPre = (kDbg & 4) != 0;
+        v2d nxt_u[G::P_INSTR], nxt_j[G::J_INSTR > 0 ? G::J_INSTR : 1];
+        auto load_regs = [&](int64_t t, int f_, bool with_j) {
+            const int64_t e0 = t * G::TEL;
+            const char* ub = reinterpret_cast<const char*>(field_in(P, f_)) + e0 * (NP * 8);
+#pragma unroll
+            for (int c = 0; c < G::P_INSTR; ++c)
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                    nxt_u[c] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(ub + tile_src_chunk<NP>(c * 64 + lane) * 16));
+            if (!with_j) return;
+#pragma unroll
+            for (int c = 0; c < G::J_INSTR; ++c) {
+                const int q = c * 64 + lane;
+                const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;
+                const char* src;
+                if constexpr (MODE == 5) {
+                    const int x = row / ND, r = row - ND * x;
+                    src = reinterpret_cast<const char*>((x == 0 ? Q->j[0] : x == 1 ? Q->j[1] : Q->j[2]) + (int64_t)r * E + e0) + col * 16;
+                } else {
+                    src = reinterpret_cast<const char*>(J) + e0 * 8 + ((int64_t)row * E) * 8 + col * 16;
+                }
+                if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) nxt_j[c] = *reinterpret_cast<const v2d*>(src);
+            }
+        };
+        auto regs_to_lds = [&](bool with_j) {
+            char* ul = reinterpret_cast<char*>(L->u[0]);
+#pragma unroll
+            for (int c = 0; c < G::P_INSTR; ++c)
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                    *reinterpret_cast<v2d*>(ul + (c * 64 + lane) * 16) = nxt_u[c];
+            if (with_j) {
+                char* jl = reinterpret_cast<char*>(L->j);
+#pragma unroll
+                for (int c = 0; c < G::J_INSTR; ++c) {
+                    const int q = c * 64 + lane;
+                    if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) *reinterpret_cast<v2d*>(jl + q * 16) = nxt_j[c];
+                }
+            }
+            wave_lds_fence();
+        };
         unsigned* const ticket = reinterpret_cast<unsigned*>(reinterpret_cast<WaveLds*>(smem)->o);   // (o is unused here)
         if constexpr (kTicket) {
             if (threadIdx.x == 0) *ticket = G::WAVES;           // tickets 0 .. W-1 are the waves' first tiles
@@ -375,7 +420,10 @@ __device__ __forceinline__ void div3d_mfma_body(
         unsigned long long dw = 0, dm = 0, de = 0, dn = 0;
         const unsigned long long dstart = (kDbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
-        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+        if (tile < tEnd && !(kDbg & 8)) {
+            if constexpr (kRegPre) { load_regs(tile, 0, true); regs_to_lds(true); }
+            else issue_loads(tile, 0, true);
+        }
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
             const bool next_new_tile = (fk + 1 == nb);
@@ -384,7 +432,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #ifdef FE_EXPERIMENTS
             const unsigned long long c0 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-            wait_vmcnt<0>();
+            if constexpr (!kRegPre) wait_vmcnt<0>();
 #ifdef FE_EXPERIMENTS
             const unsigned long long c1 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -395,6 +443,13 @@ __device__ __forceinline__ void div3d_mfma_body(
             for (int jq = 0; jq < G::KSJ; ++jq) {
                 const int j = 4 * jq + g;
                 bf[jq] = j < NP ? L->u[0][tile_index<NP>(n, j < NP ? j : 0)] : 0.0;
+            }
+            if constexpr (kRegPre) {
+                // the B values and J are in registers: ask for the next unit now (the loads land under the MFMAs)
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq) asm volatile("" : "+v"(bf[jq]));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (nt < tEnd && !(kDbg & 8)) load_regs(nt, nk, next_new_tile);
             }
             v4d acc[NC][G::BT > 0 ? G::BT : 1];
             double accs[NC][G::NS > 0 ? G::NS : 1];
@@ -469,7 +524,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                                   ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc)) : v2d{0.0, 0.0};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // plane x has left the buffer
-                if (kEarly && x == ND - 1 && nt < tEnd && !(kDbg & 8)) { issue_loads(nt, nk, next_new_tile); requested = true; }
+                if (!kRegPre && kEarly && x == ND - 1 && nt < tEnd && !(kDbg & 8)) { issue_loads(nt, nk, next_new_tile); requested = true; }
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
@@ -480,7 +535,11 @@ __device__ __forceinline__ void div3d_mfma_body(
                 }
                 wave_lds_fence();
             }
-            if (!requested && nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);   // (MODE 5: last plane not asked for)
+            if constexpr (kRegPre) {
+                if (nt < tEnd && !(kDbg & 8)) regs_to_lds(next_new_tile);   // the planes have left the buffer: the next unit moves in
+            } else if (!requested && nt < tEnd && !(kDbg & 8)) {
+                issue_loads(nt, nk, next_new_tile);   // (MODE 5: last plane not asked for)
+            }
 #ifdef FE_EXPERIMENTS
             const unsigned long long c3 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
             dw += c1 - c0; dm += c2 - c1; de += c3 - c2; ++dn;

@@ -191,7 +191,7 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
         return FE_OK;                                                                                                     \
     }
     switch (dbg) {
-        FE_P5_CASE(1) FE_P5_CASE(2) FE_P5_CASE(3) FE_P5_CASE(8) FE_P5_CASE(9) FE_P5_CASE(10) FE_P5_CASE(11) FE_P5_CASE(32) FE_P5_CASE(16) FE_P5_CASE(64) FE_P5_CASE(80)
+        FE_P5_CASE(1) FE_P5_CASE(2) FE_P5_CASE(3) FE_P5_CASE(4) FE_P5_CASE(5) FE_P5_CASE(6) FE_P5_CASE(8) FE_P5_CASE(9) FE_P5_CASE(10) FE_P5_CASE(11) FE_P5_CASE(32) FE_P5_CASE(16) FE_P5_CASE(64) FE_P5_CASE(80)
         default: break;
     }
 #undef FE_P5_CASE

@@ -84,8 +84,9 @@ static int ab_main(int argc, char** argv) {
     // variant codes >= 100000: the same variant (code - 100000) with the operator in prepared form
     void* prepared = nullptr;
     CK(hipMalloc(&prepared, FE_PREPARED_OPERATOR_BYTES));
-    FE(fe_prepare_operator(family, a.D, Np, family == FE_FAMILY_FACEMASS ? nf : 0, family == FE_FAMILY_FACEMASS ? Nfp : 0, 0,
-                           prepared, nullptr));
+    if (fe_prepare_operator(family, a.D, Np, family == FE_FAMILY_FACEMASS ? nf : 0, family == FE_FAMILY_FACEMASS ? Nfp : 0, 0,
+                            prepared, nullptr) != 0)
+        prepared = nullptr;   // (no prepared form for this shape, e.g. p = 5: variant codes >= 100000 then launch plainly)
     auto set_variant = [&](int code) {
         a.prepared = code >= 100000 ? prepared : nullptr;
         a.variant = code >= 100000 ? code - 100000 : code;
