@@ -35,8 +35,9 @@ EXPORTED_SYMBOLS = (
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
-    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim",
+    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim", "fe_launch_f32",
 )
+FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
 _c_double_p = C.c_void_p   # device pointers travel as plain integers
 
@@ -157,6 +158,8 @@ def load_library() -> C.CDLL:
     lib.fe_split_stats.argtypes = [C.c_char_p, C.c_size_t]
     lib.fe_split_trim.restype = C.c_int
     lib.fe_split_trim.argtypes = []
+    lib.fe_launch_f32.restype = C.c_int
+    lib.fe_launch_f32.argtypes = [C.c_int32, C.POINTER(ArgPack), C.c_void_p]
     lib.fe_prepare_operator.restype = C.c_int
     lib.fe_prepare_operator.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]

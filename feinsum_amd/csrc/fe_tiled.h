@@ -37,9 +37,9 @@ constexpr int kTiledMaxGroups = 64;  // element groups per tile
 constexpr int64_t kTiledLdsBudget = 160 * 1024;
 
 struct TiledArgs {
-    const double* J;     // geometry factors in the family's layout, or nullptr
-    const double* A;     // operator in the family's layout
-    FieldPtrs P;         // inputs / outputs of the nb fields
+    const void* J;       // geometry factors in the family's layout, or nullptr   (element type T of the kernel:
+    const void* A;       // operator in the family's layout                        double, or float for the
+    FieldPtrs P;         // inputs / outputs of the nb fields                      float32 einsums of round 3)
     int64_t E;
     int family;          // FE_FAMILY_GRAD / DIV / DIVCOMP / MATAPPLY / FACEMASS
     int ndim, Np, nf, Nfp, nb;
@@ -47,8 +47,8 @@ struct TiledArgs {
     int ncomp, K, KP, IW, EB, neg, TE, At_d;   // derived by tiled_plan()
 };
 
-// LDS bytes of a launch (operator + B tile + J tile), after filling in the derived fields.
-inline int64_t tiled_plan(TiledArgs& a) {
+// LDS bytes of a launch (operator + B tile + J tile), after filling in the derived fields.  esize: bytes per element.
+inline int64_t tiled_plan(TiledArgs& a, int esize = 8) {
     a.ncomp = a.family == FE_FAMILY_GRAD ? a.ndim : 1;
     a.K = a.family == FE_FAMILY_GRAD || a.family == FE_FAMILY_MATAPPLY ? a.Np
         : a.family == FE_FAMILY_DIV ? a.ndim * a.Np
@@ -60,10 +60,10 @@ inline int64_t tiled_plan(TiledArgs& a) {
     const int64_t jrows = a.family == FE_FAMILY_GRAD || a.family == FE_FAMILY_DIV ? (int64_t)a.ndim * a.ndim : 0;
     a.At_d = a.ncomp * a.K * a.Np + kTiledRows * a.IW;   // + slack: rows i >= Np are read, never stored
     a.At_d += a.At_d & 1;
-    const int64_t op_bytes = 8 * (int64_t)a.At_d;
+    const int64_t op_bytes = esize * (int64_t)a.At_d;
     int64_t bytes = 0;
     for (a.EB = 8; a.EB >= 4; a.EB /= 2) {
-        const int64_t group_bytes = 8 * (int64_t)a.EB * (a.KP + jrows);   // B rows + J columns of one element group
+        const int64_t group_bytes = esize * (int64_t)a.EB * (a.KP + jrows);   // B rows + J columns of one element group
         a.neg = kTiledThreads / a.IW;
         if (a.neg > kTiledMaxGroups) a.neg = kTiledMaxGroups;
         if (a.neg < 1) a.neg = 1;
@@ -81,16 +81,16 @@ inline int64_t tiled_plan(TiledArgs& a) {
 // acc[c][b] = sum_k A[row c of this thread, k] B[e_b, k]: ap -> At[0][0][i] (k stride Np; the thread's
 // rows are row_stride apart: K Np between grad's components, IW between output rows), bp -> the
 // thread's first B row (row stride KP, all lanes of an element group read one address)
-template <int NC, int EB>
-__device__ __forceinline__ void tiled_gemm(const double* ap, int row_stride, const double* bp, int K, int Np, int KP,
-                                           double (&acc)[kTiledRows][EB]) {
+template <int NC, int EB, typename T>
+__device__ __forceinline__ void tiled_gemm(const T* ap, int row_stride, const T* bp, int K, int Np, int KP,
+                                           T (&acc)[kTiledRows][EB]) {
 #pragma unroll
     for (int c = 0; c < kTiledRows; ++c)
 #pragma unroll
-        for (int b = 0; b < EB; ++b) acc[c][b] = 0.0;
+        for (int b = 0; b < EB; ++b) acc[c][b] = T(0);
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
-        double bv[EB], av[NC];
+        T bv[EB], av[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) av[c] = ap[c * row_stride + k * Np];
 #pragma unroll
@@ -102,12 +102,14 @@ __device__ __forceinline__ void tiled_gemm(const double* ap, int row_stride, con
     }
 }
 
-template <int EB>
+template <int EB, typename T = double>
 __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double tsm[];
-    double* At = tsm;                                        // [ncomp][K][Np]
-    double* Bt = At + a.At_d;                                // [TE][KP]
-    double* Jt = Bt + (int64_t)a.TE * a.KP;                  // [ndim * ndim][TE]  (grad, div)
+    extern __shared__ __attribute__((aligned(16))) char tsm_raw[];
+    T* At = reinterpret_cast<T*>(tsm_raw);                   // [ncomp][K][Np]
+    T* Bt = At + a.At_d;                                     // [TE][KP]
+    T* Jt = Bt + (int64_t)a.TE * a.KP;                       // [ndim * ndim][TE]  (grad, div)
+    const T* const gJ = static_cast<const T*>(a.J);
+    const T* const gA = static_cast<const T*>(a.A);
     const int tid = threadIdx.x;
     const int Np = a.Np, K = a.K, KP = a.KP, TE = a.TE, nd = a.ndim;
     const int64_t E = a.E;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                 const int r = a.family == FE_FAMILY_GRAD ? c : k / Np, j = a.family == FE_FAMILY_GRAD ? k : k % Np;
                 src = a.opT ? ((int64_t)r * Np + j) * Np + i : ((int64_t)r * Np + i) * Np + j;
             }
-            At[idx] = a.A[src];
+            At[idx] = gA[src];
         }
     }
 
@@ -149,11 +151,11 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
         if (a.family == FE_FAMILY_GRAD || a.family == FE_FAMILY_DIV)
             for (int idx = tid; idx < nd * nd * TE; idx += kTiledThreads) {
                 const int row = idx / TE, e = idx - row * TE;
-                Jt[idx] = e < te ? a.J[(int64_t)row * E + e0 + e] : 0.0;
+                Jt[idx] = e < te ? gJ[(int64_t)row * E + e0 + e] : T(0);
             }
         for (int fk = 0; fk < a.nb; ++fk) {
-            const double* __restrict__ in = field_in(a.P, fk);
-            double* __restrict__ out = field_out(a.P, fk);
+            const T* __restrict__ in = reinterpret_cast<const T*>(field_in(a.P, fk));
+            T* __restrict__ out = reinterpret_cast<T*>(field_out(a.P, fk));
             __syncthreads();   // Jt ready; previous field's B no longer read
             // ---- B tile
             if (a.family == FE_FAMILY_FACEMASS) {
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                 for (int idx = tid; idx < a.nf * per_f; idx += kTiledThreads) {
                     const int f = idx / per_f, rem = idx - f * per_f;
                     const int e = rem / a.Nfp, j = rem - e * a.Nfp;
-                    double v = 0.0;
+                    T v = T(0);
                     if (e < te) {
-                        const double jf = a.jlayout ? a.J[(int64_t)f * E + e0 + e] : a.J[(e0 + e) * a.nf + f];
+                        const T jf = a.jlayout ? gJ[(int64_t)f * E + e0 + e] : gJ[(e0 + e) * a.nf + f];
                         v = jf * in[((int64_t)f * E + e0 + e) * a.Nfp + j];
                     }
                     Bt[e * KP + f * a.Nfp + j] = v;
@@ -173,21 +175,21 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                     const int e = idx / Np, j = idx - e * Np;
                     const bool live = e < te;
                     if (a.family == FE_FAMILY_DIV) {
-                        double ju[3] = {0.0, 0.0, 0.0};
+                        T ju[3] = {T(0), T(0), T(0)};
                         for (int x = 0; x < nd; ++x) {
-                            const double ux = live ? in[((int64_t)x * E + e0 + e) * Np + j] : 0.0;
+                            const T ux = live ? in[((int64_t)x * E + e0 + e) * Np + j] : T(0);
                             for (int r = 0; r < nd; ++r) ju[r] += Jt[(x * nd + r) * TE + e] * ux;
                         }
                         for (int r = 0; r < nd; ++r) Bt[e * KP + r * Np + j] = ju[r];
                     } else {
-                        const double ue = live ? in[(e0 + e) * Np + j] : 0.0;
+                        const T ue = live ? in[(e0 + e) * Np + j] : T(0);
                         if (a.family == FE_FAMILY_DIVCOMP) {
                             for (int s = 0; s < nd; ++s) {
-                                const double js = !live ? 0.0 : a.jlayout ? a.J[(e0 + e) * nd + s] : a.J[(int64_t)s * E + e0 + e];
+                                const T js = !live ? T(0) : a.jlayout ? gJ[(e0 + e) * nd + s] : gJ[(int64_t)s * E + e0 + e];
                                 Bt[e * KP + s * Np + j] = js * ue;
                             }
                         } else if (a.family == FE_FAMILY_MATAPPLY) {
-                            Bt[e * KP + j] = (a.J && live) ? a.J[e0 + e] * ue : ue;
+                            Bt[e * KP + j] = (gJ && live) ? gJ[e0 + e] * ue : ue;
                         } else {
                             Bt[e * KP + j] = ue;   // grad
                         }
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
             __syncthreads();
             // ---- out[e, i] = sum_k A_c[i, k] B[e, k]
             if (worker) {
-                double acc[kTiledRows][EB];
-                const double* ap = At + gi;
-                const double* bp = Bt + (int64_t)eg * EB * KP;
+                T acc[kTiledRows][EB];
+                const T* ap = At + gi;
+                const T* bp = Bt + (int64_t)eg * EB * KP;
                 if (!is_grad || a.ncomp == 3) tiled_gemm<3, EB>(ap, is_grad ? K * Np : a.IW, bp, K, Np, KP, acc);
                 else if (a.ncomp == 2) tiled_gemm<2, EB>(ap, K * Np, bp, K, Np, KP, acc);
                 else tiled_gemm<1, EB>(ap, K * Np, bp, K, Np, KP, acc);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kTiledThreads) void tiled_apply_kernel(TiledArgs a)
                     const int64_t e = e0 + el;
                     if (is_grad) {
                         for (int x = 0; x < nd; ++x) {
-                            double v = Jt[(x * nd + 0) * TE + el] * acc[0][b];
+                            T v = Jt[(x * nd + 0) * TE + el] * acc[0][b];
                             if (nd > 1) v += Jt[(x * nd + 1) * TE + el] * acc[1][b];
                             if (nd > 2) v += Jt[(x * nd + 2) * TE + el] * acc[2][b];
                             out[((int64_t)x * E + e) * Np + gi] = v;

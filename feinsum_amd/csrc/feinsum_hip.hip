@@ -20,6 +20,7 @@
 #include "fe_fused.h"
 #include "fe_generic.h"
 #include "fe_grad.h"
+#include "fe_grad_f32.h"
 #include "fe_tiled.h"
 
 namespace {
@@ -248,15 +249,18 @@ constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
 
 bool tiled_fits(fe::TiledArgs a) { return a.Np >= 1 && a.Np <= fe::kTiledThreads && fe::tiled_plan(a) <= kTiledMaxLds; }
 
-int launch_tiled(fe::TiledArgs a, hipStream_t s) {
-    const int64_t lds = fe::tiled_plan(a);
+template <typename T>
+int launch_tiled_t(fe::TiledArgs a, hipStream_t s) {
+    const int64_t lds = fe::tiled_plan(a, (int)sizeof(T));
     if (a.Np > fe::kTiledThreads || lds > kTiledMaxLds)
         return fail(FE_EUNSUPPORTED, "tiled kernel: operator and tile need %lld bytes of LDS (limit %lld)",
                     (long long)lds, (long long)kTiledMaxLds);
     static PerDeviceOnce once;
     const int attr_rc = once.run([] {
-        const int rc = configure_kernel(fe::tiled_apply_kernel<8>, "tiled<8>", (int)kTiledMaxLds, fe::kTiledThreads, 1);
-        return rc != FE_OK ? rc : configure_kernel(fe::tiled_apply_kernel<4>, "tiled<4>", (int)kTiledMaxLds, fe::kTiledThreads, 1);
+        const int rc = configure_kernel(fe::tiled_apply_kernel<8, T>, sizeof(T) == 8 ? "tiled<8>" : "tiled<8> float32", (int)kTiledMaxLds,
+                                        fe::kTiledThreads, 1);
+        return rc != FE_OK ? rc : configure_kernel(fe::tiled_apply_kernel<4, T>, sizeof(T) == 8 ? "tiled<4>" : "tiled<4> float32",
+                                                   (int)kTiledMaxLds, fe::kTiledThreads, 1);
     });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = (a.E + a.TE - 1) / a.TE;
@@ -264,11 +268,12 @@ int launch_tiled(fe::TiledArgs a, hipStream_t s) {
     if (per_cu > 2048 / fe::kTiledThreads) per_cu = 2048 / fe::kTiledThreads;
     const int64_t cap = per_cu * device_cu_count();
     const dim3 grid((unsigned)(nTiles < cap ? nTiles : cap)), block(fe::kTiledThreads);
-    if (a.EB == 8) hipLaunchKernelGGL(fe::tiled_apply_kernel<8>, grid, block, (size_t)lds, s, a);
-    else hipLaunchKernelGGL(fe::tiled_apply_kernel<4>, grid, block, (size_t)lds, s, a);
+    if (a.EB == 8) hipLaunchKernelGGL((fe::tiled_apply_kernel<8, T>), grid, block, (size_t)lds, s, a);
+    else hipLaunchKernelGGL((fe::tiled_apply_kernel<4, T>), grid, block, (size_t)lds, s, a);
     FE_HIP_CHECK(hipGetLastError());
     return FE_OK;
 }
+int launch_tiled(fe::TiledArgs a, hipStream_t s) { return launch_tiled_t<double>(a, s); }
 
 // Which kernel class serves a call.  AUTO: MFMA where compiled, else the tiled kernel where the
 // operator fits in LDS, else the plain generic kernels.
@@ -1634,7 +1639,87 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
 }
 #endif
 
+int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
+    if (!a) return fail(FE_EINVAL, "fe_launch_f32: null argument pack");
+    if (a->E < 0 || a->Np <= 0) return fail(FE_EINVAL, "fe_launch_f32: bad sizes (E=%lld Np=%d)", (long long)a->E, a->Np);
+    if (a->E == 0) return FE_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ndim = a->ndim == 2 ? 2 : 3;
+    // field pointers: the b-field form (v / outs) when given, else the single pair (u / out)
+    const int b = a->b > 0 ? a->b : 1;
+    const double* const* vin = a->v;
+    double* const* vout = a->outs;
+    const double* one_in[1] = {a->u};
+    double* one_out[1] = {a->out};
+    if (!vin || !vout) {
+        if (b != 1) return fail(FE_EINVAL, "fe_launch_f32: b = %d needs the v / outs pointer arrays", b);
+        vin = one_in;
+        vout = one_out;
+    }
+    int opT = 0, jl = 0, rl = 0, nf = 0, Nfp = 0;
+    switch (family) {
+        case FE_FAMILY_GRAD:
+        case FE_FAMILY_DIV:
+        case FE_FAMILY_MATAPPLY:
+            if (a->layout_flags & ~FE_OP_TRANSPOSED) return fail(FE_EINVAL, "fe_launch_f32: bad operator flags %d", a->layout_flags);
+            opT = (a->layout_flags & FE_OP_TRANSPOSED) ? 1 : 0;
+            break;
+        case FE_FAMILY_DIVCOMP:
+            if (a->layout_flags & ~(FE_OP_TRANSPOSED | FE_OP_J_ES)) return fail(FE_EINVAL, "fe_launch_f32: bad operator flags %d", a->layout_flags);
+            opT = (a->layout_flags & FE_OP_TRANSPOSED) ? 1 : 0;
+            jl = (a->layout_flags & FE_OP_J_ES) ? 1 : 0;
+            break;
+        case FE_FAMILY_FACEMASS:
+            if (a->nf <= 0 || a->Nfp <= 0) return fail(FE_EINVAL, "fe_launch_f32: face-mass needs nf and Nfp");
+            nf = a->nf;
+            Nfp = a->Nfp;
+            jl = (a->layout_flags & FE_FM_J_FE) ? 1 : 0;
+            rl = ((a->layout_flags & FE_FM_R_IFJ) ? 1 : 0) + ((a->layout_flags & FE_FM_R_T) ? 2 : 0);
+            break;
+        default:
+            return fail(FE_EUNSUPPORTED, "fe_launch_f32: family %d has no float32 kernel", family);
+    }
+    if (!a->D || (family != FE_FAMILY_MATAPPLY && !a->J)) return fail(FE_EINVAL, "fe_launch_f32: null device pointer");
+    // grad of tetrahedra p = 4 on the matrix cores (fe_grad_f32.h): 16-byte aligned operands, E a multiple of 4 (so that
+    // every row of J and every output plane starts on a 16-byte boundary) and at least one full tile; else the tiled kernel
+    if (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35 && a->variant != FE_VARIANT_TILED && a->E % 4 == 0 && a->E >= 16) {
+        bool aligned = ((reinterpret_cast<uintptr_t>(a->J) | reinterpret_cast<uintptr_t>(a->D)) & 15u) == 0;
+        for (int k = 0; k < b; ++k)
+            aligned = aligned && vin[k] && vout[k] && ((reinterpret_cast<uintptr_t>(vin[k]) | reinterpret_cast<uintptr_t>(vout[k])) & 15u) == 0;
+        if (aligned) {
+            using G = fe::GradF32Geom;
+            static PerDeviceOnce once;
+            if (int rc = configured(once, fe::grad3d_mfma_f32_kernel, "grad float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+            const int64_t nTiles = a->E / G::TEL;
+            int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+            const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+            if (blocks > cap) blocks = cap;
+            for (int k = 0; k < b; ++k)
+                hipLaunchKernelGGL(fe::grad3d_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
+                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
+                                   reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
+    }
+    for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {   // groups of up to kMaxFields fields share the staged operator
+        const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
+        fe::FieldPtrs P = {};
+        for (int k = 0; k < nb; ++k) {
+            if (!vin[k0 + k] || !vout[k0 + k]) return fail(FE_EINVAL, "fe_launch_f32: null field pointer");
+            P.v[k] = vin[k0 + k];
+            P.out[k] = vout[k0 + k];
+        }
+        const fe::TiledArgs ta = tiled_args(family, a->J, a->D, P, family == FE_FAMILY_DIVCOMP ? 1 : nb, a->E,
+                                            family == FE_FAMILY_MATAPPLY ? 1 : ndim, a->Np, nf, Nfp, opT, jl, rl);
+        if (int rc = launch_tiled_t<float>(ta, s)) return rc;
+        if (family == FE_FAMILY_DIVCOMP) break;
+    }
+    return FE_OK;
+}
+
 static int launch_family(int32_t family, const fe_argpack* a, void* stream) {
+    if (family & FE_FAMILY_F32) return fe_launch_f32(family & ~FE_FAMILY_F32, a, stream);
     switch (family) {
         case FE_FAMILY_GRAD:
             if (a->ndim == 2)

@@ -109,8 +109,10 @@ def _match_template(einsum: BatchedEinsum, subscripts: str) -> Optional[Tuple[Tu
 
 def match_family(einsum: BatchedEinsum) -> Optional[KernelPlan]:
     """Return the :class:`KernelPlan` for *einsum*, or ``None`` if it is not a DG-family einsum."""
-    if any(dt != np.float64 for dt in einsum.arg_to_dtype.values()):
-        return None
+    dtypes = {np.dtype(dt) for dt in einsum.arg_to_dtype.values()}
+    if dtypes not in ({np.dtype("float64")}, {np.dtype("float32")}):
+        return None     # mixed or other element types: the generic einsum kernel (or none)
+    is_f32 = dtypes == {np.dtype("float32")}
     for family, flags, subscripts, roles in _TEMPLATES:
         m = _match_template(einsum, subscripts)
         if m is None:
@@ -137,6 +139,8 @@ def match_family(einsum: BatchedEinsum) -> Optional[KernelPlan]:
         else:
             params = {"Np": int(dim("i")), "nf": int(dim("f")), "Nfp": int(dim("j"))}
         del long_dim
+        if is_f32:
+            params["f32"] = 1      # all-float32 operands: fe_launch_f32 (the LDS-tiled kernel in float)
         return KernelPlan(family, flags, {role: perm[k] for k, role in enumerate(roles)},
                           mapping["e"], params)
     return None

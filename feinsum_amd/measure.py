@@ -39,6 +39,7 @@ order** (the reference draws in hash order, which is not reproducible; SURVEY H5
 from __future__ import annotations
 
 import logging
+from ctypes import byref as C_byref
 from dataclasses import dataclass, field
 from time import time
 from types import MappingProxyType
@@ -246,11 +247,12 @@ class _FamilyLaunch:
         self._keep = (arg_dict, outs)
         self._prepared: Dict[Any, Any] = {}   # (operator pointer, flags) -> prepared device buffer
         p = plan.params
+        self.f32 = bool(p.get("f32"))         # all-float32 einsum: fe_launch_f32, whatever the variant
         op_role = "D" if plan.family in (FAMILY_GRAD, FAMILY_DIV, FAMILY_DIVCOMP, FAMILY_MATAPPLY) else "R"
         self.groups = []   # list of ArgPack (one per launch)
         in_role = "u" if op_role == "D" else "v"
         self.group_family = plan.family
-        if plan.family == FAMILY_DIVCOMP and self._bind_planes(einsum, arg_dict, outs):
+        if plan.family == FAMILY_DIVCOMP and not self.f32 and self._bind_planes(einsum, arg_dict, outs):
             return
         # consecutive rows sharing J and the operator become one multi-field launch
         k = 0
@@ -293,7 +295,7 @@ class _FamilyLaunch:
         operator array in place.  Returns the number of prepared groups."""
         import torch
 
-        if self.variant not in (_hip.VARIANT_AUTO, _hip.VARIANT_MFMA, _hip.VARIANT_MFMA_SPLIT) or self.group_family == FAMILY_GRADPLANES \
+        if self.f32 or self.variant not in (_hip.VARIANT_AUTO, _hip.VARIANT_MFMA, _hip.VARIANT_MFMA_SPLIT) or self.group_family == FAMILY_GRADPLANES \
                 or self.plan.family not in (FAMILY_GRAD, FAMILY_DIV, FAMILY_FACEMASS):
             return 0
         done = 0
@@ -352,7 +354,9 @@ class _FamilyLaunch:
     def launch(self, stream_ptr: int) -> None:
         lib = _hip.load_library()
         for pack in self.groups:
-            if self.group_family == FAMILY_GRADPLANES:
+            if self.f32:
+                _hip.check(lib.fe_launch_f32(self.plan.family, C_byref(pack), stream_ptr))
+            elif self.group_family == FAMILY_GRADPLANES:
                 _hip.check(lib.fe_gradplanes3d_f64(pack.j3, pack.D, pack.v, pack.outs, pack.E, pack.Np,
                                                    pack.b, pack.layout_flags, pack.variant, stream_ptr))
             elif self.plan.family == FAMILY_GRAD and pack.prepared:
@@ -381,7 +385,8 @@ class _FamilyLaunch:
     def time_batch(self, n: int, stream_ptr: int) -> float:
         """Seconds for *n* launches of the whole batched einsum (HIP events)."""
         if len(self.groups) == 1:
-            return _hip.time_launches(self.group_family, self.groups[0], n, stream_ptr) * 1e-3
+            family = self.group_family | (_hip.FAMILY_F32 if self.f32 else 0)
+            return _hip.time_launches(family, self.groups[0], n, stream_ptr) * 1e-3
         import torch
 
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

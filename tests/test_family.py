@@ -34,10 +34,15 @@ def test_non_family():
     g = f.einsum("xre,rij,ej->xie", f.array("J", (3, 3, "E")), f.array("R", (3, 35, 35)),
                  f.array("u", ("E", 35)))
     assert f.match_family(g) is None
-    # float32 DG einsum: kernels are fp64 only
+    # all-float32 DG einsum: a family einsum too (round 3: fe_launch_f32), marked so that the float launch is taken
     g32 = f.einsum("xre,rij,ej->xei", f.array("J", (3, 3, "E"), "float32"),
                    f.array("R", (3, 35, 35), "float32"), f.array("u", ("E", 35), "float32"))
-    assert f.match_family(g32) is None
+    plan = f.match_family(g32)
+    assert plan is not None and plan.params == {"Np": 35, "ndim": 3, "f32": 1}
+    # mixed element types are not
+    gmix = f.einsum("xre,rij,ej->xei", f.array("J", (3, 3, "E"), "float32"),
+                    f.array("R", (3, 35, 35), "float64"), f.array("u", ("E", 35), "float32"))
+    assert f.match_family(gmix) is None
     # 2D grad (ndim = 2) is the grad family with ndim = 2 (tiled kernel); other ndim are not
     g2 = f.einsum("xre,rij,ej->xei", f.array("J", (2, 2, "E")), f.array("R", (2, 10, 10)),
                   f.array("u", ("E", 10)))

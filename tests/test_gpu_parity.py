@@ -707,3 +707,66 @@ def test_split_walk_is_a_div_variant_only(torch_cuda):
         dev = _device_inputs(torch, expr, 100, seed=1)
         with pytest.raises(NotImplementedError):
             f.evaluate(expr, 0, dev, transform="mfma_split", wait=True)
+
+
+# ---- float32 operands (round 3): the DG families on the LDS-tiled kernel in float --------------------
+
+def _f32(expr):
+    """The same einsum with every operand in float32."""
+    rows = [[f.array(a.name, a.shape, "float32") for a in row] for row in expr.args]
+    return f.batched_einsum(expr.get_subscripts(), rows)
+
+
+F32_CASES = {
+    "grad": lambda: dg.grad(), "grad_t": lambda: dg.grad_t(), "div": lambda: dg.div(), "face_mass": lambda: dg.face_mass(4),
+    "face_mass_ifj_fe": lambda: dg.face_mass_ifj_fe(4), "div_components": lambda: dg.batched_div_components(),
+    "batched_grad_b3": lambda: dg.batched_grad(3), "batched_div_b2": lambda: dg.batched_div(2),
+    "mass_apply_b4": lambda: dg.mass_apply(4), "operator_apply": lambda: dg.operator_apply(),
+    "grad_p3": lambda: dg.grad(20), "div_p2": lambda: dg.div(10), "grad_p5": lambda: dg.grad(56),
+    "face_mass_p5": lambda: dg.face_mass(4, Np=56, Nfp=21), "face_mass_b9": lambda: dg.face_mass(9),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(F32_CASES))
+@pytest.mark.parametrize("E", [1, 37, 1000, 10007, 70004])
+def test_float32_families(torch_cuda, name, E):
+    """All-float32 DG einsums (the reference validates float32 at 1e-6: src/feinsum/measure.py:178-192) run on the
+    matrix cores (grad p = 4 with E a multiple of 4: fe_grad_f32.h; E = 1000 has 62 tiles and 8 elements behind them,
+    at E = 70 004 every wave walks several tiles) or on the tiled kernel in float (fe_launch_f32), not on the
+    one-thread-per-entry generic einsum kernel.  Compared with the
+    float64 evaluation of the SAME float32 inputs: float32 rounding of a 105-term sum of values in [0, 1) allows ~1e-6
+    of the largest entry."""
+    torch = torch_cuda
+    from feinsum_amd.family import match_family
+    from feinsum_amd.measure import generate_host_input_arrays
+
+    expr = _f32(F32_CASES[name]())
+    plan = match_family(expr)
+    assert plan is not None and plan.params.get("f32") == 1
+    host = generate_host_input_arrays(expr, E, np_seed=E)
+    assert all(a.dtype == np.float32 for a in host.values())
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    outs = f.evaluate(expr, 0, dev, wait=True)
+    for out_name, row in zip(expr.output_names, expr.args):
+        got = outs[out_name]
+        assert got.dtype == torch.float32
+        ref = np.einsum(expr.get_subscripts(), *[host[a.name].astype(np.float64) for a in row], optimize="optimal")
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= 2e-6, (name, E, err)
+
+
+@pytest.mark.gpu
+def test_float32_validation_and_timing(torch_cuda):
+    """timeit on a float32 einsum: the reference's validation at E = 100 (atol = rtol = 1e-6) passes and the launch is
+    timed through fe_time_launches(family | FE_FAMILY_F32); float32 moves half the bytes of float64."""
+    from feinsum_amd import measure
+
+    e32, e64 = _f32(dg.grad()), dg.grad()
+    measure.validate_batched_einsum_transform(e32, 0, None)
+    t32 = measure.timeit_details(e32, cq=0, long_dim_length=200_000, min_secs=0.2)
+    gen = measure.timeit_details(e32, cq=0, long_dim_length=200_000, min_secs=0.2, transform="generic") if False else None
+    assert 0 < t32.seconds_device < 5e-3 and gen is None
+    assert measure._get_footprint_gbytes(e32, 200_000) == pytest.approx(0.5 * measure._get_footprint_gbytes(e64, 200_000))
+    rate = f.measure_giga_op_rate(e32, cq=0, long_dim_length=200_000)
+    assert set(rate) == {np.dtype("float32")} and rate[np.dtype("float32")] > 2000      # (the generic kernel: ~1000)
