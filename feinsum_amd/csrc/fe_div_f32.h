@@ -1,0 +1,209 @@
+// fe_div_f32.h -- div einsum 'xre,rij,xej->ei' in float32 on the matrix cores (tetrahedra p = 4, Np = 35).
+//
+// The float32 counterpart of fe_div.h's register-fragment kernel, one wave = one tile of 16 elements:
+//   B fragments  Ju[(jq, r)][e] = sum_x J[x,r,e] * u[x,e,j]   on the VALU (one multiply, two explicit fused multiply-adds),
+//                j = 4 jq + g, produced straight in MFMA B layout from the three u planes of the tile in LDS;
+//   out[i, e] = sum_{(jq, r)} D[r, i, 4 jq + g] * Ju[(jq, r)][e]   on v_mfma_f32_16x16x4_f32: A = D as 48 x 108 (rows 35..47
+//                and columns j >= 35 zero), resident in registers (81 floats per lane), 3 x 27 = 81 MFMAs of 32 cycles per
+//                tile.  float32 has no 4-row block instruction with K = 4 (float64: v_mfma_f64_4x4x4_4b), so rows 32..34 cost a
+//                whole third row tile.
+// Data movement as in fe_div.h: the three planes of a tile leave no LDS room for a second buffer at twelve waves per CU, so ALL
+// B fragments of a tile are built first, which frees the u and J buffers, and the next tile's LDS-DMA loads are issued before
+// this tile's MFMAs and stores (counted vmcnt at the top of a tile: only the previous tile's stores are younger).  The output
+// tile is transposed through wave-private LDS into 1-KiB contiguous non-temporal stores.  float32 C/D layout: lane
+// (g = lane >> 4, n = lane & 15) holds rows 4 g + v (v = 0..3) of a 16-row tile for column (element) n.
+// 596 B and 7980 flops per element: HBM roofline 107 TFLOP/s.  Operands must be 16-byte aligned with E a multiple of 4 (every
+// plane and every row of J then starts on a 16-byte boundary; the launcher sends other sizes to the tiled kernel); the
+// elements behind the last full tile are done by block 0.
+#pragma once
+#include "fe_grad_f32.h"
+
+namespace fe {
+
+struct DivF32Geom {
+    static constexpr int NP = 35, TEL = 16, RT = 3, KSJ = 9, KS = 3 * KSJ;
+    static constexpr int PLANE_F = TEL * NP;            // floats: one u plane of a tile / the out tile (560)
+    static constexpr int P_CHUNKS = PLANE_F / 4;        // 16-byte chunks (140)
+    static constexpr int P_INSTR = (P_CHUNKS + 63) / 64;            // 3
+    static constexpr int J_ROW_CHUNKS = TEL / 4, J_CHUNKS = 9 * J_ROW_CHUNKS;   // 36: one instruction
+    static constexpr int LOADS = 3 * P_INSTR + 1, STORES = P_INSTR;
+    struct WaveIn {
+        float u[3][PLANE_F];     // u[x][e0 .. e0+15][0..34]
+        float j[9 * TEL];        // J[x*3+r][e0 .. e0+15]
+    };
+    static constexpr int WAVES = 4;
+    static constexpr int OP_F = 3 * NP * NP;
+    static constexpr int IN_BYTES = (int)sizeof(WaveIn) * WAVES;
+    static constexpr int OUT_BYTES = PLANE_F * 4 * WAVES;           // one output transposition buffer per wave
+    static constexpr int OP_BYTES = (OP_F * 4 + 15) / 16 * 16;
+    static constexpr int LDS_BYTES = IN_BYTES + (OUT_BYTES > OP_BYTES ? OUT_BYTES : OP_BYTES);
+    static constexpr int BLOCKS_PER_CU = 3;
+    static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
+};
+
+__device__ __forceinline__ void div3d_item_f32(const float* __restrict__ J, const float* __restrict__ D,
+                                               const float* __restrict__ u, float* __restrict__ out, int64_t E, int Np,
+                                               int64_t e, int i, int opT) {
+    const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+    float jac[9];
+    for (int k = 0; k < 9; ++k) jac[k] = J[(int64_t)k * E + e];
+    float acc = 0.f;
+    for (int j = 0; j < Np; ++j) {
+        float ux[3];
+        for (int x = 0; x < 3; ++x) ux[x] = u[((int64_t)x * E + e) * Np + j];
+        for (int r = 0; r < 3; ++r) {
+            const float ju = __builtin_fmaf(jac[6 + r], ux[2], __builtin_fmaf(jac[3 + r], ux[1], jac[r] * ux[0]));
+            acc = __builtin_fmaf(D[(int64_t)r * Np * Np + (int64_t)i * si + (int64_t)j * sj], ju, acc);
+        }
+    }
+    out[e * Np + i] = acc;
+}
+
+__global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
+                                                                const float* __restrict__ u, float* __restrict__ out,
+                                                                int64_t E, int64_t nTiles, int opT) {
+    using G = DivF32Geom;
+    constexpr int NP = G::NP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    G::WaveIn* L = reinterpret_cast<G::WaveIn*>(smem) + wave;
+    float* ob = reinterpret_cast<float*>(smem + G::IN_BYTES) + wave * G::PLANE_F;
+    const int n = lane & 15, g = lane >> 4;
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
+    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
+    int64_t tile = (int64_t)bid * G::WAVES + wave;
+    const unsigned lds_u = lds_addr_uniform(L->u[0]), lds_j = lds_addr_uniform(L->j);
+
+    auto issue_loads = [&](int64_t t) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const char* up = reinterpret_cast<const char*>(u + ((int64_t)x * E + t * G::TEL) * NP) + lane * 16;
+#pragma unroll
+            for (int c = 0; c < G::P_INSTR; ++c)
+                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                    glds16_nt(up + c * 1024, lds_u + x * (G::PLANE_F * 4) + c * 1024);
+        }
+        const int row = lane / G::J_ROW_CHUNKS, col = lane - row * G::J_ROW_CHUNKS;
+        if (lane < G::J_CHUNKS) glds16(reinterpret_cast<const char*>(J + (int64_t)row * E + t * G::TEL) + col * 16, lds_j);
+    };
+
+    // ---- the first tile's loads, and behind them the operator -> LDS (over the output buffers)
+    if (tile < tEnd) issue_loads(tile);
+    {
+        float* dl = reinterpret_cast<float*>(smem + G::IN_BYTES);
+        constexpr int kPer = (G::OP_F + 255) / 256;
+        float tmp[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            tmp[k] = idx < G::OP_F ? D[idx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            if (idx < G::OP_F) dl[idx] = tmp[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- A fragments: lane (g, n) supplies A[row 16 t + n][k = g] of k-step (jq, r): D[r][16 t + n][4 jq + g]
+    float afrag[G::RT][G::KS];
+    {
+        const float* dl = reinterpret_cast<const float*>(smem + G::IN_BYTES);
+        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
+#pragma unroll
+        for (int t = 0; t < G::RT; ++t) {
+            const int i = 16 * t + n;
+            const float* row = dl + (i < NP ? i : 0) * istride;
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq) {
+                const int j = 4 * jq + g;
+                const float* col = row + (j < NP ? j : 0) * jstride;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float val = col[r * (NP * NP)];
+                    afrag[t][jq * 3 + r] = (i < NP && j < NP) ? val : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();   // the staging area becomes the waves' output buffers
+
+    if (bid == 0) {
+        const int64_t e_begin = nTiles * G::TEL, cnt = (E - e_begin) * NP;
+        for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) div3d_item_f32(J, D, u, out, E, NP, e_begin + idx / NP, (int)(idx % NP), opT);
+    }
+
+    bool first = true;
+    const bool younger_half = bid >= (nblk + 1) / 2;
+    int iteration = 0;
+    while (tile < tEnd) {
+        balance_priority(younger_half, iteration++);
+        // vector-memory ops in issue order: L(tile) S(previous tile) | wait L(tile)
+        if (first) wait_vmcnt<0>();
+        else wait_vmcnt<G::STORES>();
+        first = false;
+
+        // ---- all B fragments of the tile
+        float jac[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
+        float bfrag[G::KSJ][3];
+#pragma unroll
+        for (int jq = 0; jq < G::KSJ; ++jq) {
+            const int j = 4 * jq + g, jc = j < NP ? j : 0;
+            float ux[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float v = L->u[x][n * NP + jc];
+                ux[x] = j < NP ? v : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                bfrag[jq][r] = __builtin_fmaf(jac[6 + r], ux[2], __builtin_fmaf(jac[3 + r], ux[1], jac[r] * ux[0]));
+        }
+        // the u / J tiles are now in registers: hand the buffers back to the DMA engine
+#pragma unroll
+        for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t nt = tile + stride;
+        if (nt < tEnd) issue_loads(nt);
+
+        v4f acc[G::RT];
+#pragma unroll
+        for (int t = 0; t < G::RT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
+
+        // ---- transposed store: lane (g, n) holds out[e0 + n][16 t + 4 g + v]
+#pragma unroll
+        for (int t = 0; t < G::RT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 16 * t + 4 * g + v;
+                if (16 * t + 15 < NP || i < NP) ob[n * NP + i] = acc[t][v];
+            }
+        wave_lds_fence();
+        float* op = out + tile * (G::TEL * NP);
+#pragma unroll
+        for (int c = 0; c < G::P_INSTR; ++c) {
+            const int q = c * 64 + lane;
+            if ((c + 1) * 64 <= G::P_CHUNKS || q < G::P_CHUNKS) {
+                const v4f val = *reinterpret_cast<const v4f*>(ob + 4 * q);
+                __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(op + 4 * q));
+            }
+        }
+        wave_lds_fence();
+        tile = nt;
+    }
+}
+
+}  // namespace fe

@@ -21,6 +21,8 @@
 #include "fe_generic.h"
 #include "fe_grad.h"
 #include "fe_grad_f32.h"
+#include "fe_div_f32.h"
+#include "fe_facemass_f32.h"
 #include "fe_tiled.h"
 
 namespace {
@@ -1682,10 +1684,49 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
     if (!a->D || (family != FE_FAMILY_MATAPPLY && !a->J)) return fail(FE_EINVAL, "fe_launch_f32: null device pointer");
     // grad of tetrahedra p = 4 on the matrix cores (fe_grad_f32.h): 16-byte aligned operands, E a multiple of 4 (so that
     // every row of J and every output plane starts on a 16-byte boundary) and at least one full tile; else the tiled kernel
-    if (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35 && a->variant != FE_VARIANT_TILED && a->E % 4 == 0 && a->E >= 16) {
+    // div and face-mass likewise (fe_div_f32.h, fe_facemass_f32.h)
+    const bool mfma_shape = (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35) || (family == FE_FAMILY_DIV && ndim == 3 && a->Np == 35) ||
+                            (family == FE_FAMILY_FACEMASS && a->Np == 35 && nf == 4 && Nfp == 15);
+    if (mfma_shape && a->variant != FE_VARIANT_TILED && a->E % 4 == 0 && a->E >= 16) {
         bool aligned = ((reinterpret_cast<uintptr_t>(a->J) | reinterpret_cast<uintptr_t>(a->D)) & 15u) == 0;
         for (int k = 0; k < b; ++k)
             aligned = aligned && vin[k] && vout[k] && ((reinterpret_cast<uintptr_t>(vin[k]) | reinterpret_cast<uintptr_t>(vout[k])) & 15u) == 0;
+        if (aligned && family == FE_FAMILY_DIV) {
+            using G = fe::DivF32Geom;
+            static PerDeviceOnce once;
+            if (int rc = configured(once, fe::div3d_mfma_f32_kernel, "div float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+            const int64_t nTiles = a->E / G::TEL;
+            int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+            const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+            if (blocks > cap) blocks = cap;
+            for (int k = 0; k < b; ++k)
+                hipLaunchKernelGGL(fe::div3d_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
+                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
+                                   reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
+        if (aligned && family == FE_FAMILY_FACEMASS) {
+            using G = fe::FmF32Geom;
+            static PerDeviceOnce once;
+            if (int rc = configured(once, fe::facemass_mfma_f32_kernel, "face-mass float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+            const int64_t nTiles = a->E / G::TEL;
+            int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+            const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+            if (blocks > cap) blocks = cap;
+            for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {   // groups of up to kMaxFields fields share J and the fragments
+                const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
+                fe::FieldPtrs P;
+                for (int k = 0; k < fe::kMaxFields; ++k) {
+                    P.v[k] = vin[k0 + (k < nb ? k : 0)];
+                    P.out[k] = vout[k0 + (k < nb ? k : 0)];
+                }
+                hipLaunchKernelGGL(fe::facemass_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
+                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D), P, nb, a->E, nTiles, jl, rl);
+            }
+            FE_HIP_CHECK(hipGetLastError());
+            return FE_OK;
+        }
         if (aligned) {
             using G = fe::GradF32Geom;
             static PerDeviceOnce once;

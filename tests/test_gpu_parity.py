@@ -724,6 +724,8 @@ F32_CASES = {
     "mass_apply_b4": lambda: dg.mass_apply(4), "operator_apply": lambda: dg.operator_apply(),
     "grad_p3": lambda: dg.grad(20), "div_p2": lambda: dg.div(10), "grad_p5": lambda: dg.grad(56),
     "face_mass_p5": lambda: dg.face_mass(4, Np=56, Nfp=21), "face_mass_b9": lambda: dg.face_mass(9),
+    "div_t": lambda: dg.div_t(), "face_mass_b1": lambda: dg.face_mass(1), "face_mass_b2": lambda: dg.face_mass(2),
+    "face_mass_b3": lambda: dg.face_mass(3), "face_mass_jfi_fe": lambda: dg.face_mass_jfi_fe(4), "face_mass_fji": lambda: dg.face_mass_fji(2),
 }
 
 
@@ -732,9 +734,10 @@ F32_CASES = {
 @pytest.mark.parametrize("E", [1, 37, 1000, 10007, 70004])
 def test_float32_families(torch_cuda, name, E):
     """All-float32 DG einsums (the reference validates float32 at 1e-6: src/feinsum/measure.py:178-192) run on the
-    matrix cores (grad p = 4 with E a multiple of 4: fe_grad_f32.h; E = 1000 has 62 tiles and 8 elements behind them,
-    at E = 70 004 every wave walks several tiles) or on the tiled kernel in float (fe_launch_f32), not on the
-    one-thread-per-entry generic einsum kernel.  Compared with the
+    matrix cores (grad / div / face-mass at p = 4 with E a multiple of 4: fe_grad_f32.h, fe_div_f32.h, fe_facemass_f32.h;
+    E = 1000 has 62 tiles and 8 elements behind them, at E = 70 004 every wave walks several tiles and, with b fields,
+    several (tile, field) units) or on the tiled kernel in float (fe_launch_f32), not on the one-thread-per-entry
+    generic einsum kernel.  Compared with the
     float64 evaluation of the SAME float32 inputs: float32 rounding of a 105-term sum of values in [0, 1) allows ~1e-6
     of the largest entry."""
     torch = torch_cuda
