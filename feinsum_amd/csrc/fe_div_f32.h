@@ -3,15 +3,17 @@
 // The float32 counterpart of fe_div.h's register-fragment kernel, one wave = one tile of 16 elements:
 //   B fragments  Ju[(jq, r)][e] = sum_x J[x,r,e] * u[x,e,j]   on the VALU (one multiply, two explicit fused multiply-adds),
 //                j = 4 jq + g, produced straight in MFMA B layout from the three u planes of the tile in LDS;
-//   out[i, e] = sum_{(jq, r)} D[r, i, 4 jq + g] * Ju[(jq, r)][e]   on v_mfma_f32_16x16x4_f32: A = D as 48 x 108 (rows 35..47
-//                and columns j >= 35 zero), resident in registers (81 floats per lane), 3 x 27 = 81 MFMAs of 32 cycles per
-//                tile.  float32 has no 4-row block instruction with K = 4 (float64: v_mfma_f64_4x4x4_4b), so rows 32..34 cost a
-//                whole third row tile.
-// Data movement as in fe_div.h: the three planes of a tile leave no LDS room for a second buffer at twelve waves per CU, so ALL
-// B fragments of a tile are built first, which frees the u and J buffers, and the next tile's LDS-DMA loads are issued before
-// this tile's MFMAs and stores (counted vmcnt at the top of a tile: only the previous tile's stores are younger).  The output
-// tile is transposed through wave-private LDS into 1-KiB contiguous non-temporal stores.  float32 C/D layout: lane
+//   out[i, e] = sum_{(jq, r)} D[r, i, 4 jq + g] * Ju[(jq, r)][e]   on the matrix cores, A = D resident in registers (81 floats
+//                per lane): rows 0..31 as two 16-row tiles on v_mfma_f32_16x16x4_f32 (2 x 27 MFMAs of 32 cycles), rows 32..34
+//                on v_mfma_f32_4x4x1_16B_f32 (27 of 8 cycles, see SMALL below) -- float32 has no 4-row block instruction with
+//                K = 4 (float64: v_mfma_f64_4x4x4_4b), and a third 16-row tile for three rows costs a third of the MFMA time.
+// Data movement: the u planes and J of a tile come in by LDS-DMA into a ring of two buffers; ALL B fragments of a tile are built
+// first, which frees its buffer, and tile t + 2 is requested into it before tile t's MFMAs and stores (counted vmcnt at the top
+// of a tile: S(t-2), L(t+1), S(t-1) are younger than L(t)).  Two blocks per CU (73 KB of LDS each).  The output tile is
+// transposed through wave-private LDS into 1-KiB contiguous non-temporal stores.  float32 C/D layout: lane
 // (g = lane >> 4, n = lane & 15) holds rows 4 g + v (v = 0..3) of a 16-row tile for column (element) n.
+// Measured at E = 1e6 (profiles/r03/float32_div_facemass.txt): one buffer and three blocks per CU with three row tiles 0.1465 ms,
+// ring of two 0.1222 ms, ring of two with rows 32..34 on the 4x4x1 instruction 0.1094 ms = 73.0 TFLOP/s = 68.1 %.
 // 596 B and 7980 flops per element: HBM roofline 107 TFLOP/s.  Operands must be 16-byte aligned with E a multiple of 4 (every
 // plane and every row of J then starts on a 16-byte boundary; the launcher sends other sizes to the tiled kernel); the
 // elements behind the last full tile are done by block 0.
@@ -20,6 +22,9 @@
 
 namespace fe {
 
+// RING: 1 = one u / J buffer per wave, three blocks per CU (the next tile is requested after this tile's B fragments);
+//       2 = ring of two buffers, two blocks per CU (tile t + 2 is requested after tile t's B fragments).
+template <int RING>
 struct DivF32Geom {
     static constexpr int NP = 35, TEL = 16, RT = 3, KSJ = 9, KS = 3 * KSJ;
     static constexpr int PLANE_F = TEL * NP;            // floats: one u plane of a tile / the out tile (560)
@@ -27,9 +32,12 @@ struct DivF32Geom {
     static constexpr int P_INSTR = (P_CHUNKS + 63) / 64;            // 3
     static constexpr int J_ROW_CHUNKS = TEL / 4, J_CHUNKS = 9 * J_ROW_CHUNKS;   // 36: one instruction
     static constexpr int LOADS = 3 * P_INSTR + 1, STORES = P_INSTR;
-    struct WaveIn {
+    struct Slot {
         float u[3][PLANE_F];     // u[x][e0 .. e0+15][0..34]
         float j[9 * TEL];        // J[x*3+r][e0 .. e0+15]
+    };
+    struct WaveIn {
+        Slot s[RING];
     };
     static constexpr int WAVES = 4;
     static constexpr int OP_F = 3 * NP * NP;
@@ -37,8 +45,9 @@ struct DivF32Geom {
     static constexpr int OUT_BYTES = PLANE_F * 4 * WAVES;           // one output transposition buffer per wave
     static constexpr int OP_BYTES = (OP_F * 4 + 15) / 16 * 16;
     static constexpr int LDS_BYTES = IN_BYTES + (OUT_BYTES > OP_BYTES ? OUT_BYTES : OP_BYTES);
-    static constexpr int BLOCKS_PER_CU = 3;
+    static constexpr int BLOCKS_PER_CU = RING == 1 ? 3 : 2;
     static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
+    static_assert(2 * STORES + LOADS <= 60, "counted vmcnt must fit the 6-bit field");
 };
 
 __device__ __forceinline__ void div3d_item_f32(const float* __restrict__ J, const float* __restrict__ D,
@@ -59,23 +68,29 @@ __device__ __forceinline__ void div3d_item_f32(const float* __restrict__ J, cons
     out[e * Np + i] = acc;
 }
 
-__global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
-                                                                const float* __restrict__ u, float* __restrict__ out,
-                                                                int64_t E, int64_t nTiles, int opT) {
-    using G = DivF32Geom;
+// SMALL: rows 32..34 on v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4 x 4 x 1, 8 cycles) instead of a third 16-row tile: block
+// 4 g + n / 4 of lane (g, n) is (k-slice g, element group n / 4), so the B fragment of the 16x16x4 instruction is the B operand
+// as it is, lane (g, n) supplies A = D[r][32 + n % 4][4 jq + g] and receives in register v the k-slice-g part of
+// out[e0 + n][32 + v]; the four parts are added across the lane groups at the end of the tile.
+template <int RING, bool SMALL>
+__global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
+                                                                                const float* __restrict__ u, float* __restrict__ out,
+                                                                                int64_t E, int64_t nTiles, int opT) {
+    using G = DivF32Geom<RING>;
     constexpr int NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    G::WaveIn* L = reinterpret_cast<G::WaveIn*>(smem) + wave;
+    typename G::WaveIn* L = reinterpret_cast<typename G::WaveIn*>(smem) + wave;
     float* ob = reinterpret_cast<float*>(smem + G::IN_BYTES) + wave * G::PLANE_F;
     const int n = lane & 15, g = lane >> 4;
     const unsigned bid = blockIdx.x, nblk = gridDim.x;
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     int64_t tile = (int64_t)bid * G::WAVES + wave;
-    const unsigned lds_u = lds_addr_uniform(L->u[0]), lds_j = lds_addr_uniform(L->j);
+    const unsigned lds_s0 = lds_addr_uniform(&L->s[0]);
 
-    auto issue_loads = [&](int64_t t) {
+    auto issue_loads = [&](int64_t t, int slot) {
+        const unsigned lds_u = lds_s0 + slot * (unsigned)sizeof(typename G::Slot), lds_j = lds_u + 3 * G::PLANE_F * 4;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             const char* up = reinterpret_cast<const char*>(u + ((int64_t)x * E + t * G::TEL) * NP) + lane * 16;
@@ -88,8 +103,10 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
         if (lane < G::J_CHUNKS) glds16(reinterpret_cast<const char*>(J + (int64_t)row * E + t * G::TEL) + col * 16, lds_j);
     };
 
-    // ---- the first tile's loads, and behind them the operator -> LDS (over the output buffers)
-    if (tile < tEnd) issue_loads(tile);
+    // ---- the first tile's loads (ring of two: the first two tiles'), and behind them the operator -> LDS (over the output
+    //      buffers)
+    if (tile < tEnd) issue_loads(tile, 0);
+    if (RING == 2 && tile + stride < tEnd) issue_loads(tile + stride, 1);
     {
         float* dl = reinterpret_cast<float*>(smem + G::IN_BYTES);
         constexpr int kPer = (G::OP_F + 255) / 256;
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
         const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
 #pragma unroll
         for (int t = 0; t < G::RT; ++t) {
-            const int i = 16 * t + n;
+            const int i = (SMALL && t == 2) ? 32 + (n & 3) : 16 * t + n;
             const float* row = dl + (i < NP ? i : 0) * istride;
 #pragma unroll
             for (int jq = 0; jq < G::KSJ; ++jq) {
@@ -135,20 +152,25 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
         for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) div3d_item_f32(J, D, u, out, E, NP, e_begin + idx / NP, (int)(idx % NP), opT);
     }
 
-    bool first = true;
     const bool younger_half = bid >= (nblk + 1) / 2;
-    int iteration = 0;
+    int iteration = 0, slot = 0;
     while (tile < tEnd) {
-        balance_priority(younger_half, iteration++);
-        // vector-memory ops in issue order: L(tile) S(previous tile) | wait L(tile)
-        if (first) wait_vmcnt<0>();
-        else wait_vmcnt<G::STORES>();
-        first = false;
+        balance_priority(younger_half, iteration);
+        // vector-memory ops in issue order -- one buffer: L(t) S(t-1) | wait L(t);  ring of two: L(t) S(t-2) L(t+1) S(t-1)
+        if (RING == 1) {
+            if (iteration == 0) wait_vmcnt<0>();
+            else wait_vmcnt<G::STORES>();
+        } else {
+            if (iteration >= 2 && tile + stride < tEnd) wait_vmcnt<2 * G::STORES + G::LOADS>();
+            else wait_vmcnt<0>();
+        }
+        ++iteration;
+        const typename G::Slot* S = &L->s[slot];
 
         // ---- all B fragments of the tile
         float jac[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
+        for (int k = 0; k < 9; ++k) jac[k] = S->j[k * G::TEL + n];
         float bfrag[G::KSJ][3];
 #pragma unroll
         for (int jq = 0; jq < G::KSJ; ++jq) {
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
             float ux[3];
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                const float v = L->u[x][n * NP + jc];
+                const float v = S->u[x][n * NP + jc];
                 ux[x] = j < NP ? v : 0.f;
             }
 #pragma unroll
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
             for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int64_t nt = tile + stride;
-        if (nt < tEnd) issue_loads(nt);
+        if (tile + RING * stride < tEnd) issue_loads(tile + RING * stride, slot);
 
         v4f acc[G::RT];
 #pragma unroll
@@ -180,16 +202,27 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int t = 0; t < G::RT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
+                for (int t = 0; t < G::RT; ++t) {
+                    if (SMALL && t == 2) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
+                }
 
         // ---- transposed store: lane (g, n) holds out[e0 + n][16 t + 4 g + v]
 #pragma unroll
         for (int t = 0; t < G::RT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int i = 16 * t + 4 * g + v;
-                if (16 * t + 15 < NP || i < NP) ob[n * NP + i] = acc[t][v];
+                if (SMALL && t == 2) {
+                    if (v < NP - 32) {
+                        float x = acc[t][v];
+                        x += __shfl_xor(x, 16);
+                        x += __shfl_xor(x, 32);
+                        if (g == 0) ob[n * NP + 32 + v] = x;
+                    }
+                } else {
+                    const int i = 16 * t + 4 * g + v;
+                    if (16 * t + 15 < NP || i < NP) ob[n * NP + i] = acc[t][v];
+                }
             }
         wave_lds_fence();
         float* op = out + tile * (G::TEL * NP);
@@ -203,6 +236,7 @@ __global__ __launch_bounds__(256, 3) void div3d_mfma_f32_kernel(const float* __r
         }
         wave_lds_fence();
         tile = nt;
+        if (RING == 2) slot ^= 1;
     }
 }
 

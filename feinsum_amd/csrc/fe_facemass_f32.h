@@ -48,6 +48,8 @@ struct FmF32Geom {
 __device__ __forceinline__ const float* field_in_f32(const FieldPtrs& P, int k) { return reinterpret_cast<const float*>(field_in(P, k)); }
 __device__ __forceinline__ float* field_out_f32(const FieldPtrs& P, int k) { return reinterpret_cast<float*>(field_out(P, k)); }
 
+// SMALL: rows 32..34 on v_mfma_f32_4x4x1_16B_f32 instead of a third 16-row tile (see fe_div_f32.h).
+template <bool SMALL>
 __global__ __launch_bounds__(256, 3) void facemass_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ R,
                                                                    FieldPtrs P, int nb, int64_t E, int64_t nTiles, int jfe,
                                                                    int rlayout) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 3) void facemass_mfma_f32_kernel(const float* 
             joff[ks] = jfe ? f * G::TEL + n : n * NF + f;
 #pragma unroll
             for (int t = 0; t < G::RT; ++t) {
-                const int i = 16 * t + n;
+                const int i = (SMALL && t == 2) ? 32 + (n & 3) : 16 * t + n;
                 const float a = rl[f * sF + (i < NP ? i : 0) * sI + j * sJ];
                 afrag[t][ks] = i < NP ? a : 0.f;
             }
@@ -185,15 +187,27 @@ __global__ __launch_bounds__(256, 3) void facemass_mfma_f32_kernel(const float* 
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < G::RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+            for (int t = 0; t < G::RT; ++t) {
+                if (SMALL && t == 2) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+            }
 
         // ---- transposed store: lane (g, n) holds out[e0 + n][16 t + 4 g + v]
 #pragma unroll
         for (int t = 0; t < G::RT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int i = 16 * t + 4 * g + v;
-                if (16 * t + 15 < NP || i < NP) ob[n * NP + i] = acc[t][v];
+                if (SMALL && t == 2) {
+                    if (v < NP - 32) {
+                        float x = acc[t][v];
+                        x += __shfl_xor(x, 16);
+                        x += __shfl_xor(x, 32);
+                        if (g == 0) ob[n * NP + 32 + v] = x;
+                    }
+                } else {
+                    const int i = 16 * t + 4 * g + v;
+                    if (16 * t + 15 < NP || i < NP) ob[n * NP + i] = acc[t][v];
+                }
             }
         wave_lds_fence();
         float* op = field_out_f32(P, fk) + tile * (G::TEL * NP);

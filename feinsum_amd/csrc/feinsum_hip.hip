@@ -1692,24 +1692,47 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
         for (int k = 0; k < b; ++k)
             aligned = aligned && vin[k] && vout[k] && ((reinterpret_cast<uintptr_t>(vin[k]) | reinterpret_cast<uintptr_t>(vout[k])) & 15u) == 0;
         if (aligned && family == FE_FAMILY_DIV) {
-            using G = fe::DivF32Geom;
-            static PerDeviceOnce once;
-            if (int rc = configured(once, fe::div3d_mfma_f32_kernel, "div float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
-            const int64_t nTiles = a->E / G::TEL;
-            int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
-            const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
-            if (blocks > cap) blocks = cap;
-            for (int k = 0; k < b; ++k)
-                hipLaunchKernelGGL(fe::div3d_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
-                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
-                                   reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
-            FE_HIP_CHECK(hipGetLastError());
-            return FE_OK;
+            // the measured alternatives (profiles/r03/float32_div_facemass.txt) stay selectable in the experiment build
+#ifdef FE_EXPERIMENTS
+            static const int ring = [] { const char* e = getenv("FEINSUM_F32_DIV_RING"); return e && atoi(e) == 1 ? 1 : 2; }();
+            static const int small = [] { const char* e = getenv("FEINSUM_F32_SMALL"); return e ? atoi(e) : 1; }();
+#else
+            constexpr int ring = 2, small = 1;
+#endif
+            const int64_t nTiles = a->E / 16;
+            auto go = [&](auto geom, auto kernel, const char* what, PerDeviceOnce& once) -> int {
+                using G = decltype(geom);
+                if (int rc = configured(once, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+                const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+                if (blocks > cap) blocks = cap;
+                for (int k = 0; k < b; ++k)
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s, reinterpret_cast<const float*>(a->J),
+                                       reinterpret_cast<const float*>(a->D), reinterpret_cast<const float*>(vin[k]),
+                                       reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+                FE_HIP_CHECK(hipGetLastError());
+                return FE_OK;
+            };
+            static PerDeviceOnce once2;
+#ifdef FE_EXPERIMENTS
+            static PerDeviceOnce once1, once3;
+            if (ring == 1) return go(fe::DivF32Geom<1>{}, fe::div3d_mfma_f32_kernel<1, false>, "div float32 Np=35 one buffer", once1);
+            if (!small) return go(fe::DivF32Geom<2>{}, fe::div3d_mfma_f32_kernel<2, false>, "div float32 Np=35 three row tiles", once3);
+#endif
+            return go(fe::DivF32Geom<2>{}, fe::div3d_mfma_f32_kernel<2, true>, "div float32 Np=35", once2);
         }
         if (aligned && family == FE_FAMILY_FACEMASS) {
             using G = fe::FmF32Geom;
             static PerDeviceOnce once;
-            if (int rc = configured(once, fe::facemass_mfma_f32_kernel, "face-mass float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+            auto kernel = fe::facemass_mfma_f32_kernel<true>;
+            const char* what = "face-mass float32 Np=35";
+            PerDeviceOnce* flag = &once;
+#ifdef FE_EXPERIMENTS
+            static const int small = [] { const char* e = getenv("FEINSUM_F32_SMALL"); return e ? atoi(e) : 1; }();
+            static PerDeviceOnce once3;
+            if (!small) { kernel = fe::facemass_mfma_f32_kernel<false>; what = "face-mass float32 Np=35 three row tiles"; flag = &once3; }
+#endif
+            if (int rc = configured(*flag, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
             const int64_t nTiles = a->E / G::TEL;
             int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
             const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
@@ -1721,8 +1744,8 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
                     P.v[k] = vin[k0 + (k < nb ? k : 0)];
                     P.out[k] = vout[k0 + (k < nb ? k : 0)];
                 }
-                hipLaunchKernelGGL(fe::facemass_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
-                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D), P, nb, a->E, nTiles, jl, rl);
+                hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s, reinterpret_cast<const float*>(a->J),
+                                   reinterpret_cast<const float*>(a->D), P, nb, a->E, nTiles, jl, rl);
             }
             FE_HIP_CHECK(hipGetLastError());
             return FE_OK;

@@ -358,11 +358,11 @@ typedef struct fe_argpack {
 /* float32 operands (the reference validates float32 einsums at 1e-6 and carries float32 peaks:
  * src/feinsum/measure.py:178-192, src/feinsum/data/device_info.py:5-26).  One entry point for the families
  * FE_FAMILY_GRAD / DIV / DIVCOMP / MATAPPLY / FACEMASS: every pointer of `args` is read as float (the struct's
- * `double` types are nominal here), layouts, `ndim` and `layout_flags` as for the float64 entry points; `variant` and
- * `prepared` is ignored.  grad of tetrahedra p = 4 (Np = 35, ndim 3) runs on v_mfma_f32_16x16x4_f32 (fe_grad_f32.h) when
- * its operands are 16-byte aligned and E is a multiple of 4 (`variant` FE_VARIANT_TILED forces the tiled kernel);
- * everything else runs on the LDS-tiled VALU kernel in float (fe_tiled.h), any shape whose operator fits in LDS
- * (FE_EUNSUPPORTED otherwise). */
+ * `double` types are nominal here), layouts, `ndim` and `layout_flags` as for the float64 entry points; `prepared` is
+ * ignored.  grad, div and face-mass of tetrahedra p = 4 (Np = 35, ndim 3; face-mass: nf = 4, Nfp = 15, any b, every layout)
+ * run on v_mfma_f32_16x16x4_f32 (fe_grad_f32.h, fe_div_f32.h, fe_facemass_f32.h) when their operands are 16-byte aligned
+ * and E is a multiple of 4 (`variant` FE_VARIANT_TILED forces the tiled kernel); everything else runs on the LDS-tiled VALU
+ * kernel in float (fe_tiled.h), any shape whose operator fits in LDS (FE_EUNSUPPORTED otherwise). */
 int fe_launch_f32(int32_t family, const fe_argpack* args, void* stream);
 
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed
