@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
-    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim", "fe_launch_f32",
+    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -158,6 +158,8 @@ def load_library() -> C.CDLL:
     lib.fe_split_stats.argtypes = [C.c_char_p, C.c_size_t]
     lib.fe_split_trim.restype = C.c_int
     lib.fe_split_trim.argtypes = []
+    lib.fe_set_tail_rounds.restype = C.c_int
+    lib.fe_set_tail_rounds.argtypes = [C.c_int32]
     lib.fe_launch_f32.restype = C.c_int
     lib.fe_launch_f32.argtypes = [C.c_int32, C.POINTER(ArgPack), C.c_void_p]
     lib.fe_prepare_operator.restype = C.c_int
@@ -381,3 +383,9 @@ def time_launches(family: int, pack: ArgPack, n_launches: int, stream: int = 0) 
 
 def einsum_generic(desc: EinsumDesc, operands: Sequence[int], out: int, stream: int = 0) -> None:
     check(load_library().fe_einsum_generic(C.byref(desc), _ptr_array(operands), out, stream))
+
+
+def set_tail_rounds(rounds: int) -> int:
+    """Number of dynamic rounds at the end of the persistent walks (fe_set_tail_rounds; negative: static walk); returns the
+    previous value.  A tuning knob -- results do not depend on it."""
+    return int(load_library().fe_set_tail_rounds(int(rounds)))

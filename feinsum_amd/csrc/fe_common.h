@@ -92,6 +92,77 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- dynamic walk: tile tickets behind two static rounds ------------------------------------------------
+// A static walk (tile = first + k * stride) ends ragged: per-wave end times of the p = 4 grad kernel at E = 1e6 spread over
+// 164 ... 190 us around a mean of 176 (profiles/r02/stamps_plain.csv) -- the slower XCDs, the younger wave of each SIMD, the
+// waves with one tile more, the part of an array that lies in the slower class of physical memory -- and the launch lasts
+// until the last wave.  Tickets for every tile from ONE or eight per-XCD counters, taken synchronously, were measured in round
+// 1 and cost more than they gave (gfx950 executes global atomics at the memory side: ~88 per us and counter, against ~330
+// tiles per us).  What works (profiles/r03/dynamic_walk_*.txt: grad E = 1e6 77.8 -> 80.6 % of the roofline, 69.2 -> 76.4 %
+// with every array from torch):
+//  * every wave walks `t_static / waves` rounds (two) statically, so that the first ticket's latency hides behind a tile;
+//  * the tiles [t_static, nTiles) are dealt out by kTailPools counters: pool p holds the tiles t_static + p + kTailPools * t,
+//    and a block's pool is (bid / 8) % kTailPools, so that every pool is drained by waves of all eight XCDs and empties at the
+//    machine's average pace (no stealing needed); 4 pools are too few (75.5 %), 8 and 16 measure alike;
+//  * one returning atomic per tile, requested ONE TILE AHEAD -- at the top of the iteration that prefetches the tile before
+//    -- so that its latency never shows;
+//  * the wave whose ticket comes back beyond the pool stops asking and reports to the pool's second counter; the last of the
+//    pool's waves to do so zeroes both: the counters are all zero between launches, whatever stream or graph replays the
+//    launch.  (One report counter for the whole grid was measured first: 2048 atomics on one address take ~23 us, E = 1e5
+//    went from 24 to 40 us.)
+// Below five rounds (E = 1e5: three) the static walk is faster (61.1 against 57.5 %) and stays.  Results do not depend on the
+// walk: a tile's arithmetic is position independent (bitwise equal outputs: tests/test_gpu_parity.py).
+constexpr int kTailPools = 16;
+constexpr int kTailStride = 2176;                        // unsigned per pool: tickets, and 4352 bytes behind them the reports
+constexpr int kTailWords = kTailPools * kTailStride;
+// One returning add of 1 by lane 0.  The value comes back microseconds later, while the wave works on: it must land where
+// the compiler keeps nothing and copies nothing.  Seen in the ISA: with an inline-asm atomic whose result is a C++ variable
+// the register allocator copies the not yet written register in front of our counted wait; the compiler's own atomic is
+// followed by vmcnt(0) at once (the merge of the one-lane branch), which drains stores and prefetches every tile; an
+// accumulation register as the landing place makes the allocator spread the kernel's values over AGPRs.  So the result lands
+// in a VGPR the compiler cannot allocate: kernels with a dynamic tail are compiled with FE_TAIL_KERNEL_ATTR
+// (amdgpu_num_vgpr(248): the compiler has v0..v247), and the statements below name v255 (tickets) and v254 (the report) in
+// their text and clobber lists, which also makes the kernel descriptor allocate all 256 registers.
+#define FE_TAIL_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(248)))
+template <int R>
+__device__ __forceinline__ void tail_request(unsigned* counter) {
+    static_assert(R == 0 || R == 1, "0: ticket (v255), 1: report (v254)");
+    unsigned long long keep;
+    unsigned one = 1u;
+    if (R == 0)
+        asm volatile(
+            "s_mov_b64 %0, exec\n\t"
+            "s_mov_b64 exec, 1\n\t"
+            "global_atomic_add v255, %1, %2, off sc0\n\t"
+            "s_mov_b64 exec, %0"
+            : "=&s"(keep) : "v"(counter), "v"(one) : "memory", "v255");
+    else
+        asm volatile(
+            "s_mov_b64 %0, exec\n\t"
+            "s_mov_b64 exec, 1\n\t"
+            "global_atomic_add v254, %1, %2, off sc0\n\t"
+            "s_mov_b64 exec, %0"
+            : "=&s"(keep) : "v"(counter), "v"(one) : "memory", "v254");
+}
+// wait until at most N vector-memory operations are outstanding (the ones issued after the request), then the value
+template <int N, int R>
+__device__ __forceinline__ unsigned tail_wait() {
+    unsigned t;
+    if (R == 0) asm volatile("s_waitcnt vmcnt(%1)\n\ts_nop 0\n\tv_readfirstlane_b32 %0, v255" : "=s"(t) : "n"(N) : "memory", "v255");
+    else asm volatile("s_waitcnt vmcnt(%1)\n\ts_nop 0\n\tv_readfirstlane_b32 %0, v254" : "=s"(t) : "n"(N) : "memory", "v254");
+    return t;
+}
+
+// ticket t of pool `pool` -> tile index, -1 beyond the last tile.  In 32-bit arithmetic on purpose (tile counts are far below
+// 2^31): for the 64-bit form `x < tEnd ? x : tEnd` of wave-uniform values hipcc 7.2 emitted v_cmp_lt_i64 (VCC) followed by
+// s_cselect_b32 (SCC, left over from the address addition) -- every ticket of the face-mass kernel read as "beyond the pool".
+__device__ __forceinline__ int64_t tail_ticket_tile(unsigned t, int64_t t_static, int pool, int64_t n_tiles) {
+    const unsigned room = (unsigned)(n_tiles - t_static);          // dynamic tiles
+    const unsigned off = t * (unsigned)kTailPools + (unsigned)pool;
+    const bool ok = t < (1u << 26) && off < room;
+    return ok ? t_static + (int64_t)off : (int64_t)-1;
+}
+
 // Orders this wave's LDS accesses for the compiler.  The hardware executes one
 // wave's DS instructions in issue order, so wave-private LDS staging needs no
 // s_barrier -- only a compiler fence between the writes of some lanes and the

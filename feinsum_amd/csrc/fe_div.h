@@ -116,12 +116,16 @@ struct DivGeom {
 // the whole prepared buffer, see fe_common.h) -- the big-tile fragments by coalesced loads straight
 // into registers, the 4-row groups copied as they are into their LDS table; D is still needed by the
 // remainder code.
-template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>
+// kDyn (plain single-field div of tetrahedra, register fragments): behind two static rounds the tiles come by tickets
+// (fe_common.h, dynamic walk); `tail` = the launch's counters (null: static walk), `t_static` = statically walked tiles.
+template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false,
+          bool kDyn = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, const FieldPtrs& P,
     int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
-    const GradFields* __restrict__ Q = nullptr) {
+    const GradFields* __restrict__ Q = nullptr, unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
+    static_assert(!kDyn || (MODE == 0 && ND == 3 && !ALDS && !W8 && !kPrep), "dynamic walk: plain div of tetrahedra");
     // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
@@ -586,12 +590,21 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
+    // dynamic walk (one field, plain walk): vector-memory ops of an iteration in issue order [ticket or report] L(next) S(this),
+    // so the counted wait at the top of a tile is that of the static walk; the ticket asked for in front of L(next) is read
+    // one iteration later at the same place
+    const bool dyn = kDyn && tail != nullptr && t_static < nTiles && nb == 1 && !split_walk;   // grid-uniform
+    const int pool = (bid >> 3) & (kTailPools - 1);
+    unsigned* const counter = tail + pool * kTailStride;
+    unsigned* const done = counter + kTailStride / 2;
+    bool pending = false, reported = false;
+    auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
     while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
         const int64_t e0 = phys(tile) * G::TEL;
         double* const out = field_out(P, fk);
         const bool next_new_tile = (fk + 1 == nb);
-        const int64_t nt = next_new_tile ? tile + stride : tile;
+        int64_t nt = next_new_tile ? tile + stride : tile;
         const int nk = next_new_tile ? 0 : fk + 1;
         // issue order: ... L(unit) [MFMAs(unit-1)] S(unit-1) | wait L(unit): the previous unit's stores are younger
         if (first || (kDbg & 10)) wait_vmcnt<0>();
@@ -646,6 +659,26 @@ __device__ __forceinline__ void div3d_mfma_body(
             for (int m = 0; m < M; ++m)
 #pragma unroll
                 for (int k = 0; k < ND * ND; ++k) asm volatile("" : "+v"(jkeep[m][k]));
+        }
+        if constexpr (kDyn) {
+            if (dyn) {
+                if (pending) {   // asked for one iteration ago, in front of this tile's loads: it is here
+                    const unsigned t = tail_wait<G::STORES, 0>();
+                    nt = tail_ticket_tile(t, t_static, pool, tEnd);
+                    pending = false;
+                    if (nt < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done);
+                        reported = true;
+                    }
+                } else {
+                    nt = static_next(tile);
+                }
+                if (nt >= 0 && static_next(nt) < 0) {   // the tile after next is not static
+                    tail_request<0>(counter);
+                    pending = true;
+                }
+                if (nt < 0) nt = tEnd;
+            }
         }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
 
@@ -773,6 +806,26 @@ __device__ __forceinline__ void div3d_mfma_body(
         fk = nk;
         tile = nt;
     }
+    if constexpr (kDyn) {
+        // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch
+        if (reported) {
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
+            const unsigned before = tail_wait<G::STORES, 1>();
+            if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// the plain single-field div with a dynamic walk (see fe_common.h)
+template <int NP, int M>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int64_t E, int64_t nTiles, int opT,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, 1, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
+                                                                tail, t_static);
 }
 
 template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>

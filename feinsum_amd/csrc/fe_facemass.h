@@ -97,11 +97,17 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
 // kPrep (register-resident fragments only): the A fragments come from a prepared operator (`prep` =
 // the whole prepared buffer: fragments ks BT + t of the 16-row tiles, then BT KS + ks NS + q of the
 // 4-row groups); no LDS staging and no block barrier.  R itself is still needed by the remainder code.
-template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false>
+// kDyn (register fragments, NB >= 3): behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk): the
+// ticket for the next tile is asked for with unit 0 of a tile and read with unit NB - 2, whose prefetch is the next tile's
+// first unit; `tail` = the launch's counters (null: static walk), `t_static` = statically walked tiles.
+template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false,
+          bool kDyn = false>
 __device__ __forceinline__ void facemass_mfma_body(
     const double* __restrict__ J, const double* __restrict__ R, const void* __restrict__ prep, const FieldPtrs& P,
-    int64_t E, int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk) {
+    int64_t E, int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk,
+    unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || !ALDS, "prepared operators: fragments in registers");
+    static_assert(!kDyn || (NB >= 3 && !ALDS && !W8 && !kPrep), "dynamic walk: three or more fields, fragments in registers");
     using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
@@ -275,15 +281,26 @@ __device__ __forceinline__ void facemass_mfma_body(
     double jv[M][G::KS];
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0;
-    for (int64_t tile = first; tile < tEnd; tile += stride) {
+    const bool dyn = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
+    const int pool = (bid >> 3) & (kTailPools - 1);
+    unsigned* const counter = tail + pool * kTailStride;
+    unsigned* const done = counter + kTailStride / 2;
+    bool reported = false;
+    int64_t tile = first;
+    while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
+        // the next tile: tile + stride in the static walk; with tickets: asked for at unit 0, known from unit NB - 2 on
+        const bool next_static = !dyn || (tile < t_static && tile + stride < t_static);
+        int64_t nt = next_static ? tile + stride : tEnd;
+        bool requested = false;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            // ---- wait for this unit's loads; younger ops: S(m-2), L(m+1), S(m-1)
+            // ---- wait for this unit's loads; younger ops: S(m-2), [the ticket asked for in unit m-1,] L(m+1), S(m-1)
             const bool next_is_tile_start = (k + 1 == NB);
-            const bool has_next = !next_is_tile_start || (tile + stride < tEnd);
+            const bool has_next = !next_is_tile_start || (nt < tEnd);
             if (warm && has_next) {
                 if (next_is_tile_start) wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS + G::J_INSTR>();
+                else if (kDyn && k == 1 && requested) wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS + 1>();
                 else wait_vmcnt<2 * G::UNIT_STORES + G::UNIT_LOADS>();
             } else {
                 wait_vmcnt<0>();
@@ -311,10 +328,27 @@ __device__ __forceinline__ void facemass_mfma_body(
                 for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(bfrag[m][ks]));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+            if constexpr (kDyn) {
+                if (k == 0 && !next_static) {   // the next tile comes by ticket
+                    tail_request<0>(counter);
+                    requested = true;
+                }
+                if (k == NB - 2 && requested) {
+                    // younger than the request: the loads and stores of units 0 .. NB - 3 (at most; this unit has waited for more)
+                    constexpr int kYounger = (NB - 2) * (G::UNIT_LOADS + G::UNIT_STORES);
+                    const unsigned t = tail_wait<(kYounger < 56 ? kYounger : 56), 0>();
+                    const int64_t x = tail_ticket_tile(t, t_static, pool, tEnd);
+                    nt = x >= 0 ? x : tEnd;
+                    if (x < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done);
+                        reported = true;
+                    }
+                }
+            }
             // ---- prefetch unit m+2 into the slot just drained
             {
                 const int k2 = (k + 2) % NB;   // folds after unrolling
-                const int64_t tile2 = tile + stride * ((k + 2) / NB);
+                const int64_t tile2 = (k + 2 < NB) ? tile : nt;
                 if (tile2 < tEnd) {
                     if (k2 == 0)
                         fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[k2], E, tile2, lane,
@@ -370,7 +404,29 @@ __device__ __forceinline__ void facemass_mfma_body(
             }
             slot ^= 1;
         }
+        tile = nt;
     }
+    if constexpr (kDyn) {
+        // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch (younger than its
+        // report: the stores of the last two units)
+        if (reported) {
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
+            const unsigned before = tail_wait<2 * G::UNIT_STORES, 1>();
+            if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// the launch of fields in registers with a dynamic walk (see fe_common.h)
+template <int NP, int NFP, int M, int NB>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void facemass_mfma_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int64_t nTiles, int jfe, int rlayout,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    facemass_mfma_body<NP, NFP, M, NB, kFmNf, false, false, false, true>(J, R, nullptr, P, E, nTiles, jfe, rlayout, blockIdx.x,
+                                                                         gridDim.x, tail, t_static);
 }
 
 template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false>

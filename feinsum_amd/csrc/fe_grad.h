@@ -199,10 +199,14 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 // kPrep: the A fragments come from a prepared operator (fe_prepare_operator; `prep` = its grad
 // section) instead of being rebuilt from D: no LDS staging, no block barrier -- the waves of a block
 // never meet.  D itself is still needed by the remainder code.
-template <int NP, int M, int kDbg = 0, bool kPlain = true, bool kPrep = false>
+// kDyn (plain single-field launches): the LAST rounds of the walk are handed out by tickets -- see "dynamic tail" below;
+// `tail` = the launch's ticket counters (null: static walk), `t_static` = number of statically walked tiles.
+template <int NP, int M, int kDbg = 0, bool kPlain = true, bool kPrep = false, bool kDyn = false>
 __device__ __forceinline__ void grad3d_mfma_body(
     const GradFields& P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx_, int64_t E,
-    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk) {
+    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk, unsigned* __restrict__ tail = nullptr,
+    int64_t t_static = 0) {
+    static_assert(!kDyn || (kPlain && M == 1 && !kPrep), "dynamic tail: plain launches of one field, one sub-tile per tile");
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -224,6 +228,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // experiment (kDbg & 128): the walk covers both halves of the element range at once (see fe_div.h, kDbg & 4)
     const int64_t half_tiles = (nTiles + 1) / 2;
     auto phys = [&](int64_t t) -> int64_t { return (kDbg & 128) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
+    const bool dyn = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
     bool pre = false;   // unit 1 already requested
     // the loads of this wave's first two units (behind the operator copy / the fragment loads)
     auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
@@ -235,7 +240,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
             pre = true;
             return 1;
         }
-        if (tile + stride < tEnd) {
+        if (tile + stride < (dyn ? t_static : tEnd)) {
             grad_issue_u<NP, M, kNT>(P.u[0], phys(tile + stride), lane, lds_addr_uniform(L->u[1]));
             grad_issue_j<NP, M, kPlain>(P, E, phys(tile + stride), lane, lds_addr_uniform(L->j[1]));
             pre = true;
@@ -300,49 +305,14 @@ __device__ __forceinline__ void grad3d_mfma_body(
         }
     });
 
-    int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
-    bool first = true;
-#ifdef FE_EXPERIMENTS
-    unsigned long long c0 = 0, r0 = 0;
-    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
-    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
-    int iteration = 0, fk = 0;
-    while (tile < tEnd) {
-        balance_priority(younger_half, iteration++);
-        // Vector-memory ops in issue order: L(unit) S(previous unit) L(next unit) | wait L(unit).
-        // The stores of the previous unit and the loads of the next one are younger than this
-        // unit's loads and stay in flight.
-        const bool next_new_tile = (fk + 1 == nb);
-        const int64_t nt = next_new_tile ? tile + stride : tile;
-        const int nk = next_new_tile ? 0 : fk + 1;
-        if (kDbg & 8) {
-            wait_vmcnt<0>();
-        } else if (nt < tEnd) {
-            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]));
-            if (next_new_tile) {
-                if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
-                if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
-                else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
-            } else {
-                if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
-                else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
-            }
-        } else {
-            if (first || (kDbg & 2)) wait_vmcnt<0>();
-            else wait_vmcnt_planes<0, G::PLANE_STORES>(nx);
-        }
-        first = false;
-        pre = false;
-
-        const double* ut = L->u[ub];
-        const double* jt = L->j[jbuf];
+    // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
+    auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt) {
         double* out_x[3];
         out_x[0] = grad_plane_out(P, fk, 0);
         out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
         out_x[2] = kPlain ? out_x[0] + 2 * E * NP : grad_plane_out(P, fk, 2);
         int obuf = 0;
-        const int64_t e0 = phys(tile) * G::TEL;
+        const int64_t e0 = phys(tile_) * G::TEL;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             // ---- stage 1 on sub-tile m
@@ -402,6 +372,120 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 wave_lds_fence();
             }
         }
+    };
+
+    if constexpr (kDyn) {
+        if (dyn) {
+            // ---- walk with a dynamic tail (fe_common.h): static tiles first + k stride below t_static, then tickets.
+            //      Vector-memory ops of an iteration in issue order: [A = ticket for the tile after next] L(next) S(cur);
+            //      every wave has a static first tile (t_static >= number of waves).
+            constexpr int NL = G::LOADS, NS = G::STORES;
+            const int pool = (bid >> 3) & (kTailPools - 1);
+            unsigned* const counter = tail + pool * kTailStride;
+            unsigned* const done = counter + kTailStride / 2;   // the pool's report counter, half a stride behind its tickets
+            // waves of this pool: blocks b with (b / 8) % kTailPools == pool
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 +
+                                         (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
+            const unsigned pool_waves = pool_blocks * G::WAVES;
+            auto ticket_tile = [&](unsigned t) -> int64_t { return tail_ticket_tile(t, t_static, pool, tEnd); };
+            auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
+            int64_t cur = tile, nxt = static_next(tile);   // nxt >= 0: requested by the prologue (pre)
+            bool pending = false, reported = false, prev_pre = false, first = true;
+            if (nxt < 0) {   // one static round: the prologue's ticket, behind L(cur)
+                tail_request<0>(counter);
+                pending = true;
+            }
+            int buf = 0, iteration = 0;
+            const bool younger_half = bid >= (nblk + 1) / 2;
+            while (cur >= 0) {
+                balance_priority(younger_half, iteration++);   // dyn
+                bool extra = false;   // one more vector-memory op (ticket or report) issued in this iteration
+                if (pending) {   // the next tile comes from a ticket: younger than it are L(cur) and S(previous)
+                    const unsigned t = first ? tail_wait<0, 0>() : prev_pre ? tail_wait<NS, 0>() : tail_wait<NL + NS, 0>();
+                    nxt = ticket_tile(t);
+                    pending = false;
+                    if (nxt < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done);
+                        reported = true;
+                        extra = true;
+                    }
+                }
+                if (nxt >= 0) {
+                    if (static_next(nxt) < 0) {   // the tile after next is not static
+                        tail_request<0>(counter);
+                        pending = true;
+                        extra = true;
+                    }
+                    if (!pre) {
+                        grad_issue_u<NP, M, kNT>(P.u[0], nxt, lane, lds_addr_uniform(L->u[buf ^ 1]));
+                        grad_issue_j<NP, M, kPlain>(P, E, nxt, lane, lds_addr_uniform(L->j[buf ^ 1]));
+                    }
+                }
+                // wait L(cur): younger are S(previous), the ticket / report, L(next)
+                if (nxt >= 0) {
+                    if (first) { if (extra) wait_vmcnt<NL + 1>(); else wait_vmcnt<NL>(); }
+                    else { if (extra) wait_vmcnt<NS + NL + 1>(); else wait_vmcnt<NS + NL>(); }
+                } else {
+                    if (first) { if (extra) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+                    else { if (extra) wait_vmcnt<NS + 1>(); else wait_vmcnt<NS>(); }
+                }
+                compute_unit(cur, 0, L->u[buf], L->j[buf]);
+                first = false;
+                prev_pre = pre;
+                pre = false;
+                cur = nxt;
+                buf ^= 1;
+                if (cur >= 0 && !pending) nxt = static_next(cur);
+            }
+            // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch (its own report is
+            // older than its last tile's stores; nobody else touches this pool's counters any more)
+            if (reported) {
+                const unsigned before = tail_wait<NS, 1>();
+                if (before + 1 == pool_waves && lane == 0) {
+                    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+    }
+
+    int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
+    bool first = true;
+#ifdef FE_EXPERIMENTS
+    unsigned long long c0 = 0, r0 = 0;
+    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
+    int iteration = 0, fk = 0;
+    while (tile < tEnd) {
+        balance_priority(younger_half, iteration++);
+        // Vector-memory ops in issue order: L(unit) S(previous unit) L(next unit) | wait L(unit).
+        // The stores of the previous unit and the loads of the next one are younger than this
+        // unit's loads and stay in flight.
+        const bool next_new_tile = (fk + 1 == nb);
+        const int64_t nt = next_new_tile ? tile + stride : tile;
+        const int nk = next_new_tile ? 0 : fk + 1;
+        if (kDbg & 8) {
+            wait_vmcnt<0>();
+        } else if (nt < tEnd) {
+            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]));
+            if (next_new_tile) {
+                if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
+                if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
+                else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
+            } else {
+                if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
+                else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
+            }
+        } else {
+            if (first || (kDbg & 2)) wait_vmcnt<0>();
+            else wait_vmcnt_planes<0, G::PLANE_STORES>(nx);
+        }
+        first = false;
+        pre = false;
+
+        compute_unit(tile, fk, L->u[ub], L->j[jbuf]);
         fk = nk;
         tile = nt;
         ub ^= 1;
@@ -427,6 +511,14 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
     GradFields P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx, int64_t E,
     int64_t nTiles, int opT) {
     grad3d_mfma_body<NP, M, kDbg, kPlain, kPrep>(P, D, prep, nb, nx, E, nTiles, opT, blockIdx.x, gridDim.x);
+}
+
+// the plain single-field launch with a dynamic tail (see fe_common.h)
+template <int NP, int kDbg = 0>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void grad3d_mfma_tail_kernel(
+    GradFields P, const double* __restrict__ D, int64_t E, int64_t nTiles, int opT, unsigned* __restrict__ tail,
+    int64_t t_static) {
+    grad3d_mfma_body<NP, 1, kDbg, true, false, true>(P, D, nullptr, 1, 3, E, nTiles, opT, blockIdx.x, gridDim.x, tail, t_static);
 }
 
 // The grad section of a prepared operator: fragment f = t * KS + ks of lane (g, n) is

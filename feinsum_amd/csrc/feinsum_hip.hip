@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -143,6 +144,57 @@ int check_common(const void* J, const void* D, const void* u, const void* out, i
 }
 
 unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 256); }
+
+// ---- dynamic walk (fe_common.h): the ticket counters of a launch.  One zeroed buffer of kTailSlots slots per device, taken
+// the first time a launch wants it (not during stream capture: then, and when the allocation fails, the launch walks
+// statically); launches take the slots in turn, so that launches running at the same time on different streams have their
+// own counters; a launch leaves its slot zeroed.
+constexpr int kTailSlots = 64;
+struct TailBuffers {
+    std::mutex lock;
+    unsigned* base[64] = {};
+    bool failed[64] = {};
+    std::atomic<unsigned> next[64];
+};
+TailBuffers g_tail;
+unsigned* tail_slot(hipStream_t s, int sets = 1) {   // `sets` consecutive counter sets (fused launches: one per body)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_tail.base[dev]) {
+        std::lock_guard<std::mutex> guard(g_tail.lock);
+        if (!g_tail.base[dev] && !g_tail.failed[dev]) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+                (void)hipGetLastError();
+                return nullptr;   // try again at the next launch outside a capture
+            }
+            unsigned* p = nullptr;
+            const size_t bytes = (size_t)kTailSlots * fe::kTailWords * sizeof(unsigned);
+            if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                g_tail.failed[dev] = true;
+                return nullptr;
+            }
+            g_tail.base[dev] = p;
+        }
+    }
+    if (!g_tail.base[dev] || sets < 1 || sets > 4) return nullptr;
+    // slots are handed out in groups of four, so that a launch with up to four counter sets has them side by side
+    const unsigned group = g_tail.next[dev].fetch_add(1) % (kTailSlots / 4);
+    return g_tail.base[dev] + (size_t)group * 4 * fe::kTailWords;
+}
+// Number of statically walked tiles of a launch of `waves` waves: two rounds, the rest by tickets (FEINSUM_TAIL_ROUNDS /
+// fe_set_tail_rounds: at most so many full rounds by tickets; negative: none); launches of fewer than five rounds walk
+// statically (E = 1e5 on 2048 waves: three rounds, measured slower with tickets).
+std::atomic<int> g_tail_rounds{[] { const char* e = getenv("FEINSUM_TAIL_ROUNDS"); return e ? atoi(e) : (1 << 20); }()};
+int64_t tail_static_tiles(int64_t nTiles, int64_t waves) {
+    const int dyn_rounds = g_tail_rounds.load(std::memory_order_relaxed);
+    const int64_t rounds = nTiles / waves;
+    if (dyn_rounds < 0 || rounds < 5) return nTiles;
+    int64_t ks = rounds - dyn_rounds;
+    if (ks < 2) ks = 2;
+    return ks * waves;
+}
 
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
@@ -366,10 +418,25 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
         case 128: FE_GRAD_CASE(128); break;
 #endif
         default:
-            if (gsec)
+            if (gsec) {
                 hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 0, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
                                    E, nTiles, opT);
-            else FE_GRAD_CASE(0);
+                break;
+            }
+            if constexpr (NP == 35 && M == 1) {
+                if (nb == 1) {   // the last rounds of the walk by tickets (fe_common.h: dynamic tail)
+                    const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                    unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+                    if (tail) {
+                        static PerDeviceOnce once_tail;
+                        if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP>, "grad Np=35 M=1, dynamic walk", G::LDS_BYTES, 256, 2))
+                            return rc;
+                        hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
+                        break;
+                    }
+                }
+            }
+            FE_GRAD_CASE(0);
             break;
     }
 #undef FE_GRAD_CASE
@@ -418,10 +485,26 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 8: FE_DIV_CASE(8); break;
 #endif
         default:
-            if (prep)
+            if (prep) {
                 hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, 0, 3, false, false, true>), g, b, G::LDS_BYTES, s, J, D,
                                    prep, P, nb, E, nTiles, opT, 0);
-            else FE_DIV_CASE(0);
+                break;
+            }
+            if constexpr (NP == 35) {
+                if (nb == 1 && !(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h)
+                    const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                    unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+                    if (tail) {
+                        static PerDeviceOnce once_tail;
+                        if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, "div Np=35, dynamic walk", G::LDS_BYTES, 256,
+                                                G::BLOCKS_PER_CU))
+                            return rc;
+                        hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, E, nTiles, opT, tail, t_static);
+                        break;
+                    }
+                }
+            }
+            FE_DIV_CASE(0);
             break;
     }
 #undef FE_DIV_CASE
@@ -510,6 +593,20 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
         if (prep) {
             hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>), dim3((unsigned)blocks),
                                dim3(G::THREADS), G::LDS_BYTES, s, J, R, prep, P, E, nTiles, jfe, rifj);
+            return FE_OK;
+        }
+    }
+    if constexpr (NP == 35 && NFP == 15 && M == 1 && NF == fe::kFmNf && !ALDS && (NB == 3 || NB == 4)) {
+        // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
+        const int64_t t_static = tail_static_tiles(nTiles, blocks * G::WAVES);
+        unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+        if (tail) {
+            static PerDeviceOnce once_tail;
+            snprintf(what, sizeof(what), "face-mass Np=35 b=%d, dynamic walk", NB);
+            if (int rc = configured(once_tail, fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>, what, G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
+                return rc;
+            hipLaunchKernelGGL((fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s,
+                               J, R, P, E, nTiles, jfe, rifj, tail, t_static);
             return FE_OK;
         }
     }
@@ -1640,6 +1737,11 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
     return FE_OK;
 }
 #endif
+
+int fe_set_tail_rounds(int32_t rounds) {
+    const int before = g_tail_rounds.exchange(rounds);
+    return before;
+}
 
 int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
     if (!a) return fail(FE_EINVAL, "fe_launch_f32: null argument pack");

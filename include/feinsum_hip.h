@@ -365,6 +365,12 @@ typedef struct fe_argpack {
  * kernel in float (fe_tiled.h), any shape whose operator fits in LDS (FE_EUNSUPPORTED otherwise). */
 int fe_launch_f32(int32_t family, const fe_argpack* args, void* stream);
 
+/* Dynamic walk of the persistent kernels (feinsum_amd/csrc/fe_common.h): behind two statically walked rounds the tiles are
+ * handed to the waves by tickets.  Sets the largest number of full rounds handed out that way for later launches of this
+ * process (default: all, or the environment's FEINSUM_TAIL_ROUNDS; negative = static walk) and returns the previous value.
+ * A tuning knob: results do not depend on it (every tile's arithmetic is position independent). */
+int fe_set_tail_rounds(int32_t rounds);
+
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed
  * by HIP events recorded on that same stream; blocks until the last one is
  * done and returns the elapsed milliseconds of the whole batch in *ms_out.

@@ -773,3 +773,34 @@ def test_float32_validation_and_timing(torch_cuda):
     assert measure._get_footprint_gbytes(e32, 200_000) == pytest.approx(0.5 * measure._get_footprint_gbytes(e64, 200_000))
     rate = f.measure_giga_op_rate(e32, cq=0, long_dim_length=200_000)
     assert set(rate) == {np.dtype("float32")} and rate[np.dtype("float32")] > 2000      # (the generic kernel: ~1000)
+
+
+# ---- dynamic walk (round 3): tiles by tickets behind two static rounds ---------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["grad", "div", "face_mass", "face_mass_b3"])
+def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
+    """Launches of five or more rounds hand their tiles to the waves by tickets (feinsum_amd/csrc/fe_common.h: dynamic walk):
+    which wave computes a tile depends on timing, the result does not -- bitwise the static walk's at sizes around the
+    switch (E = 163 840 is five rounds of 2048 waves), with tiles left over, with a remainder behind the last tile, and in
+    launches of alternating sizes one after the other (a launch must leave its ticket counters zeroed: a stale count would
+    skip tiles of the next one)."""
+    torch = torch_cuda
+    from feinsum_amd import _hip
+
+    expr = {"grad": dg.grad, "div": dg.div, "face_mass": lambda: dg.face_mass(4), "face_mass_b3": lambda: dg.face_mass(3)}[name]()
+    sizes = [163_840, 163_856, 200_003, 700_001, 163_840, 1_000_000, 180_000]
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        for E in sizes:
+            dev = _device_inputs(torch, expr, E, seed=E % 1000)
+            _hip.set_tail_rounds(-1)
+            static = {k: v.clone() for k, v in f.evaluate(expr, 0, dev, wait=True).items()}
+            for rounds in (1 << 20, 3):
+                _hip.set_tail_rounds(rounds)
+                for _ in range(3):
+                    dynamic = f.evaluate(expr, 0, dev, wait=True)
+                    for out_name in static:
+                        assert torch.equal(static[out_name], dynamic[out_name]), (name, E, rounds, out_name)
+    finally:
+        _hip.set_tail_rounds(before)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""
+A/B in one process: the persistent walk with a static tail (rounds < 0) against dynamic tails of 1 ... 12 rounds
+(fe_set_tail_rounds), on the SAME arrays -- outputs from the split allocator and from torch allocations.
+
+    python tools/tail_ab.py [grad|div|facemass] [E=1000000] [rounds="-1 1 2 3 6 12"]
+"""
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import dg  # noqa: E402
+import feinsum_amd as f  # noqa: E402
+from feinsum_amd import _hip, measure, placement  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "grad"
+E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
+rounds = [int(r) for r in (sys.argv[3] if len(sys.argv) > 3 else "-1 1 2 3 6 12").split()]
+expr = {"grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4)}[what]()
+nbytes = measure._get_footprint_gbytes(expr, E) * 1e9
+host = measure.generate_host_input_arrays(expr, E, np_seed=0)
+dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+
+
+def timed(bound, q, n):
+    bound.time_batch(10, q.stream_ptr)
+    return sorted(bound.time_batch(n, q.stream_ptr) / n for _ in range(5))[2]
+
+
+n = max(20, min(400, int(4e7 / E)))
+for label, split in (("split allocator", True), ("torch allocations", False)):
+    outs = measure.generate_out_arrays(0, expr, E, split=split)
+    q, bound, _ = measure._bind(expr, 0, dev, outs, None)
+    _hip.set_tail_rounds(-1)
+    timed(bound, q, 5 * n)   # settle
+    for rep in range(3):
+        cells = []
+        for r in rounds:
+            _hip.set_tail_rounds(r)
+            t = timed(bound, q, n)
+            cells.append(f"{r:4d}: {t * 1e6:7.2f} us ({nbytes / t / 8e12 * 100:4.1f} %)")
+        print(f"{what} E={E} {label}: " + "  ".join(cells), flush=True)
+    _hip.set_tail_rounds(-1)
+    f.evaluate(expr, 0, dev, out_dict=outs, wait=True)
+    ref = {k: v.clone() for k, v in outs.items()}
+    _hip.set_tail_rounds(1 << 20)
+    f.evaluate(expr, 0, dev, out_dict=outs, wait=True)
+    print("  dynamic tail gives the same bits:", all(torch.equal(outs[k], ref[k]) for k in ref), flush=True)
