@@ -41,11 +41,22 @@ struct GradDivGeom {
     static constexpr int LDS_BYTES = cmax<GradGeom<NP, MG>::LDS_BYTES, DivGeom<NP, MD>::LDS_BYTES>();
 };
 
+// The dynamic walk of a fused launch (fe_common.h): every body has its own set of ticket counters (kTailWords apart: div,
+// grad, lift) and its own number of statically walked tiles; a null `tail` is the static walk.
+struct FusedTail {
+    unsigned* tail;
+    int64_t static_d, static_g, static_f;
+};
+__device__ __forceinline__ unsigned* fused_tail_set(const FusedTail& t, int set) { return t.tail ? t.tail + set * kTailWords : nullptr; }
+
 // kPrep: both bodies take their A fragments from the prepared operator `prep` (fe_prepare_operator).
-template <int NP, int MG, int MD, bool kPrep = false>
-__global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
+// kDyn (plain operators, p = 4): the bodies walk dynamically when `ft.tail` is given.
+template <int NP, int MG, int MD, bool kPrep = false, bool kDyn = false>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_kernel(
     const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, GradFields Pg,
-    FieldPtrs Pd, int64_t E, int64_t nTilesG, int64_t nTilesD, int opT) {
+    FieldPtrs Pd, int64_t E, int64_t nTilesG, int64_t nTilesD, int opT, FusedTail ft) {
+    unsigned* const tail_d = fused_tail_set(ft, 0);
+    unsigned* const tail_g = fused_tail_set(ft, 1);
     // Body order (opT bits 8, 9; kFusedOrder below is what the launchers pass).  All blocks running div, then grad puts a
     // read-heavy phase (div: 76 % of its bytes are reads) in front of a write-heavy one (grad: 70 % writes); with the younger
     // half of the grid running grad FIRST each CU holds one block of either kind and the device sees the blend all the
@@ -69,15 +80,17 @@ __global__ __launch_bounds__(256, 2) void graddiv3d_mfma_kernel(
     }
 #endif
     if (!swap) {
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x);
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x,
+                                                                    nullptr, tail_d, ft.static_d);
         body_boundary();
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
-                                                 nTilesG, op, blockIdx.x, gridDim.x);
+        grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
+                                                       nTilesG, op, blockIdx.x, gridDim.x, tail_g, ft.static_g);
     } else {
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
-                                                 nTilesG, op, blockIdx.x, gridDim.x);
+        grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
+                                                       nTilesG, op, blockIdx.x, gridDim.x, tail_g, ft.static_g);
         body_boundary();
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x);
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x,
+                                                                    nullptr, tail_d, ft.static_d);
     }
 }
 
@@ -100,27 +113,31 @@ struct WaveOpArgs {
     int order;           // 0: every block div, grad, lift; 3: the younger half of the grid grad, div, lift
 };
 
-template <int NP, int NFP, int MG, int MD, int MF, int NB, bool kPrep = false>
-__global__ __launch_bounds__(256, 2) void waveop3d_mfma_kernel(WaveOpArgs a, GradFields Pg, FieldPtrs Pd,
-                                                               FieldPtrs Pf) {
+template <int NP, int NFP, int MG, int MD, int MF, int NB, bool kPrep = false, bool kDyn = false>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void waveop3d_mfma_kernel(WaveOpArgs a, GradFields Pg, FieldPtrs Pd,
+                                                                                   FieldPtrs Pf, FusedTail ft) {
+    unsigned* const tail_d = fused_tail_set(ft, 0);
+    unsigned* const tail_g = fused_tail_set(ft, 1);
+    unsigned* const tail_f = fused_tail_set(ft, 2);
+    constexpr bool kDynF = kDyn && NB >= 3;   // the lift's tickets are asked for at unit 0 and read at unit NB - 2
     // order 3: the younger half of the grid runs grad before div (see graddiv3d_mfma_kernel); the lift comes last everywhere
     const bool swap = a.order == 3 && blockIdx.x >= gridDim.x / 2;
     if (!swap) {
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
-                                                              gridDim.x);
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
+                                                                    gridDim.x, nullptr, tail_d, ft.static_d);
         body_boundary();
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
-                                                 a.nTilesG, 0, blockIdx.x, gridDim.x);
+        grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
+                                                       a.nTilesG, 0, blockIdx.x, gridDim.x, tail_g, ft.static_g);
     } else {
-        grad3d_mfma_body<NP, MG, 0, true, kPrep>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
-                                                 a.nTilesG, 0, blockIdx.x, gridDim.x);
+        grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
+                                                       a.nTilesG, 0, blockIdx.x, gridDim.x, tail_g, ft.static_g);
         body_boundary();
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
-                                                              gridDim.x);
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
+                                                                    gridDim.x, nullptr, tail_d, ft.static_d);
     }
     body_boundary();
-    facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe,
-                                                                    a.rlayout, blockIdx.x, gridDim.x);
+    facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep, kDynF>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe,
+                                                                           a.rlayout, blockIdx.x, gridDim.x, tail_f, ft.static_f);
 }
 
 }  // namespace fe

@@ -725,26 +725,35 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     static PerDeviceOnce once_plain, once_prepared;
     char what[64];
     int attr_rc;
+    constexpr bool kDyn = NP == 35 && MG == 1 && MD == 1;   // bodies with a dynamic walk (fe_common.h)
     if (prep) {
         snprintf(what, sizeof(what), "div + grad Np=%d, prepared operator", NP);
         attr_rc = configured(once_prepared, fe::graddiv3d_mfma_kernel<NP, MG, MD, true>, what, G::LDS_BYTES, 256, 2);
     } else {
         snprintf(what, sizeof(what), "div + grad Np=%d", NP);
-        attr_rc = configured(once_plain, fe::graddiv3d_mfma_kernel<NP, MG, MD>, what, G::LDS_BYTES, 256, 2);
+        attr_rc = configured(once_plain, fe::graddiv3d_mfma_kernel<NP, MG, MD, false, kDyn>, what, G::LDS_BYTES, 256, 2);
     }
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t nTiles = nTilesG > nTilesD ? nTilesG : nTilesD;
     const unsigned grid = persistent_grid(nTiles, 4);
-    int op_arg = kFusedOrderGradDiv << 8;   // see fe_fused.h
+    fe::FusedTail ft = {nullptr, nTilesD, nTilesG, 0};
+    if (kDyn && !prep) {
+        ft.static_d = tail_static_tiles(nTilesD, (int64_t)grid * 4);
+        ft.static_g = tail_static_tiles(nTilesG, (int64_t)grid * 4);
+        if (ft.static_d < nTilesD || ft.static_g < nTilesG) ft.tail = tail_slot(s, 2);
+    }
+    // body order (fe_fused.h): with the static walk the younger half of the grid runs grad first; with tickets every block
+    // runs div, then grad (profiles/r03/dynamic_walk_fused.txt: 77.9 - 78.1 against 76.9 - 77.6 %)
+    int op_arg = (ft.tail ? 0 : kFusedOrderGradDiv) << 8;
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
 #endif
     if (prep)
         hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD, true>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, prep,
-                           Pg, Pd, E, nTilesG, nTilesD, op_arg);
+                           Pg, Pd, E, nTilesG, nTilesD, op_arg, ft);
     else
-        hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr,
-                           Pg, Pd, E, nTilesG, nTilesD, op_arg);
+        hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD, false, kDyn>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr,
+                           Pg, Pd, E, nTilesG, nTilesD, op_arg, ft);
     return FE_OK;
 }
 
@@ -753,6 +762,7 @@ template <int NP, int NFP, int MG, int MD, int MF, int NB>
 int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe::FieldPtrs& Pd,
                      const fe::FieldPtrs& Pf, hipStream_t s) {
     using G = fe::WaveOpGeom<NP, NFP, MG, MD, MF>;
+    constexpr bool kDyn = NP == 35 && NFP == 15 && MG == 1 && MD == 1 && MF == 1;   // bodies with a dynamic walk (fe_common.h)
     static PerDeviceOnce once_plain, once_prepared;
     char what[80];
     int attr_rc;
@@ -761,17 +771,30 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
         attr_rc = configured(once_prepared, fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>, what, G::LDS_BYTES, 256, 2);
     } else {
         snprintf(what, sizeof(what), "div + grad + face-mass Np=%d b=%d", NP, NB);
-        attr_rc = configured(once_plain, fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>, what, G::LDS_BYTES, 256, 2);
+        attr_rc = configured(once_plain, fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, false, kDyn>, what, G::LDS_BYTES, 256, 2);
     }
     if (attr_rc != FE_OK) return attr_rc;
     int64_t nTiles = a.nTilesG > a.nTilesD ? a.nTilesG : a.nTilesD;
     if (a.nTilesF > nTiles) nTiles = a.nTilesF;
+    const unsigned grid = persistent_grid(nTiles, 4);
+    fe::FusedTail ft = {nullptr, a.nTilesD, a.nTilesG, a.nTilesF};
+    if (kDyn && !(a.prepD && a.prepR)) {
+        ft.static_d = tail_static_tiles(a.nTilesD, (int64_t)grid * 4);
+        ft.static_g = tail_static_tiles(a.nTilesG, (int64_t)grid * 4);
+        ft.static_f = NB >= 3 ? tail_static_tiles(a.nTilesF, (int64_t)grid * 4) : a.nTilesF;
+        if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
+    }
+    fe::WaveOpArgs args = a;
+    if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
+#ifdef FE_EXPERIMENTS
+    if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);
+#endif
     if (a.prepD && a.prepR)
-        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>), dim3(persistent_grid(nTiles, 4)),
-                           dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
+        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, true>), dim3(grid), dim3(256), G::LDS_BYTES, s, args, Pg,
+                           Pd, Pf, ft);
     else
-        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB>), dim3(persistent_grid(nTiles, 4)),
-                           dim3(256), G::LDS_BYTES, s, a, Pg, Pd, Pf);
+        hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, false, kDyn>), dim3(grid), dim3(256), G::LDS_BYTES, s,
+                           args, Pg, Pd, Pf, ft);
     return FE_OK;
 }
 
