@@ -124,6 +124,7 @@ constexpr int kTailWords = kTailPools * kTailStride;
 // (amdgpu_num_vgpr(248): the compiler has v0..v247), and the statements below name v255 (tickets) and v254 (the report) in
 // their text and clobber lists, which also makes the kernel descriptor allocate all 256 registers.
 #define FE_TAIL_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(248)))
+#define FE_TAIL_KERNEL_ATTR_TIGHT __attribute__((amdgpu_num_vgpr(254)))   // kernels that need all but the two ticket registers
 template <int R>
 __device__ __forceinline__ void tail_request(unsigned* counter) {
     static_assert(R == 0 || R == 1, "0: ticket (v255), 1: report (v254)");

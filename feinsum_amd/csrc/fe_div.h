@@ -125,7 +125,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
     const GradFields* __restrict__ Q = nullptr, unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
-    static_assert(!kDyn || (MODE == 0 && ND == 3 && !ALDS && !W8 && !kPrep), "dynamic walk: plain div of tetrahedra");
+    static_assert(!kDyn || (MODE == 0 && ND == 3 && !ALDS && !W8 && !kPrep) || (MODE == 4 && ND == 3 && W8),
+                  "dynamic walk: plain div of tetrahedra, or the eight-wave grad by components (p = 5)");
     // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
@@ -267,6 +268,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         static_assert(ND == 3, "three planes");
         bool first = true;
         int fk = 0;
+        // (tickets -- fe_common.h, dynamic walk -- were measured here too: 46.9 against 48.1 TFLOP/s, profiles/r03/dynamic_walk_p5.txt)
         if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
@@ -428,15 +430,29 @@ __device__ __forceinline__ void div3d_mfma_body(
             if constexpr (kRegPre) { load_regs(tile, 0, true); regs_to_lds(true); }
             else issue_loads(tile, 0, true);
         }
+        // dynamic walk (fe_common.h; one field): the ticket for the next tile is asked for at the top of a tile and read behind
+        // its last plane, where the next tile's loads are issued
+        const bool dyn8 = kDyn && tail != nullptr && t_static < nTiles && nb == 1;   // grid-uniform
+        const int pool8 = (bid >> 3) & (kTailPools - 1);
+        unsigned* const counter8 = tail + pool8 * kTailStride;
+        unsigned* const done8 = counter8 + kTailStride / 2;
+        bool reported8 = false;
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
             const bool next_new_tile = (fk + 1 == nb);
-            const int64_t nt = next_new_tile ? (kTicket ? next_ticket_tile() : tile + stride) : tile;
+            int64_t nt = next_new_tile ? (kTicket ? next_ticket_tile() : tile + stride) : tile;
             const int nk = next_new_tile ? 0 : fk + 1;
 #ifdef FE_EXPERIMENTS
             const unsigned long long c0 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
             if constexpr (!kRegPre) wait_vmcnt<0>();
+            bool asked8 = false;
+            if constexpr (kDyn) {
+                if (dyn8 && !(tile < t_static && tile + stride < t_static)) {   // the next tile is not static
+                    tail_request<0>(counter8);
+                    asked8 = true;
+                }
+            }
 #ifdef FE_EXPERIMENTS
             const unsigned long long c1 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -539,6 +555,16 @@ __device__ __forceinline__ void div3d_mfma_body(
                 }
                 wave_lds_fence();
             }
+            if constexpr (kDyn) {
+                if (asked8) {   // younger than the request: this tile's stores
+                    const int64_t x = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, pool8, tEnd);
+                    nt = x >= 0 ? x : tEnd;
+                    if (x < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done8);
+                        reported8 = true;
+                    }
+                }
+            }
             if constexpr (kRegPre) {
                 if (nt < tEnd && !(kDbg & 8)) regs_to_lds(next_new_tile);   // the planes have left the buffer: the next unit moves in
             } else if (!requested && nt < tEnd && !(kDbg & 8)) {
@@ -550,6 +576,16 @@ __device__ __forceinline__ void div3d_mfma_body(
 #endif
             fk = nk;
             tile = nt;
+        }
+        if constexpr (kDyn) {
+            if (reported8) {   // the last wave of a pool to report leaves the pool's counters zeroed
+                const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool8));
+                const unsigned before = tail_wait<0, 1>();
+                if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                    __hip_atomic_store(counter8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
 #ifdef FE_EXPERIMENTS
         if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) {
@@ -826,6 +862,16 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_ke
     unsigned* __restrict__ tail, int64_t t_static) {
     div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, 1, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
                                                                 tail, t_static);
+}
+
+// grad by components in eight-wave blocks (p = 5) with a dynamic walk (nb is a run-time argument although the launcher passes
+// 1: with the constant the compiler restructures the loop and needs 256 registers and scratch instead of ~200)
+template <int NP>
+__global__ __launch_bounds__(512, 1) FE_TAIL_KERNEL_ATTR void grad_w8_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    div3d_mfma_body<NP, 1, 0, 4, 3, true, true, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr, tail,
+                                                             t_static);
 }
 
 template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false>

@@ -107,7 +107,8 @@ __device__ __forceinline__ void facemass_mfma_body(
     int64_t E, int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk,
     unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || !ALDS, "prepared operators: fragments in registers");
-    static_assert(!kDyn || (NB >= 3 && !ALDS && !W8 && !kPrep), "dynamic walk: three or more fields, fragments in registers");
+    static_assert(!kDyn || (NB >= 3 && !ALDS && !W8 && !kPrep) || (NB >= 2 && ALDS && W8),
+                  "dynamic walk: three or more fields with the fragments in registers, or the eight-wave blocks (p = 5)");
     using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     static_assert(NB >= 2 && NB <= kMaxFields, "2..8 fields per launch");
@@ -208,10 +209,26 @@ __device__ __forceinline__ void facemass_mfma_body(
         //      buffer -> stores -> request the next unit
         fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
         double jv8[G::KS];
-        for (int64_t tile = first; tile < tEnd; tile += stride) {
+        // dynamic walk (fe_common.h): the ticket for the next tile is asked for with unit 0 (behind the vmcnt(0) at its top)
+        // and read behind the last unit's stores, where the next tile's first unit is requested
+        const bool dyn8 = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
+        const int pool8 = (bid >> 3) & (kTailPools - 1);
+        unsigned* const counter8 = tail + pool8 * kTailStride;
+        unsigned* const done8 = counter8 + kTailStride / 2;
+        bool reported8 = false;
+        int64_t tile = first;
+        while (tile < tEnd) {
+            int64_t nt = tile + stride;
+            bool asked8 = false;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 wait_vmcnt<0>();
+                if constexpr (kDyn) {
+                    if (k == 0 && dyn8 && !(tile < t_static && tile + stride < t_static)) {   // the next tile is not static
+                        tail_request<0>(counter8);
+                        asked8 = true;
+                    }
+                }
                 if (k == 0) {
 #pragma unroll
                     for (int ks = 0; ks < G::KS; ++ks) jv8[ks] = L->j[joff[ks]];
@@ -262,10 +279,32 @@ __device__ __forceinline__ void facemass_mfma_body(
                 }
                 wave_lds_fence();
                 // ---- the next unit: the next field of this tile, or field 0 (and J) of the next tile
-                if (k + 1 < NB)
+                if (k + 1 < NB) {
                     fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[(k + 1) % NB], E, tile, lane, lds_v0, lds_j, jfe);
-                else if (tile + stride < tEnd)
-                    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, tile + stride, lane, lds_v0, lds_j, jfe);
+                } else {
+                    if constexpr (kDyn) {
+                        if (asked8) {   // younger than the request by now: this unit's stores (every unit starts with vmcnt(0))
+                            const int64_t x = tail_ticket_tile(tail_wait<G::UNIT_STORES, 0>(), t_static, pool8, tEnd);
+                            nt = x >= 0 ? x : tEnd;
+                            if (x < 0) {   // this wave's pool is empty: stop asking, report
+                                tail_request<1>(done8);
+                                reported8 = true;
+                            }
+                        }
+                    }
+                    if (nt < tEnd) fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, nt, lane, lds_v0, lds_j, jfe);
+                }
+            }
+            tile = nt;
+        }
+        if constexpr (kDyn) {
+            if (reported8) {   // the last wave of a pool to report leaves the pool's counters zeroed
+                const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool8));
+                const unsigned before = tail_wait<0, 1>();
+                if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                    __hip_atomic_store(counter8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         return;
@@ -418,6 +457,15 @@ __device__ __forceinline__ void facemass_mfma_body(
             }
         }
     }
+}
+
+// eight-wave blocks with the fragments in LDS (p = 5) with a dynamic walk
+template <int NP, int NFP, int NB>
+__global__ __launch_bounds__(512, 1) FE_TAIL_KERNEL_ATTR void facemass_w8_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int64_t nTiles, int jfe, int rlayout,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    facemass_mfma_body<NP, NFP, 1, NB, kFmNf, true, true, false, true>(J, R, nullptr, P, E, nTiles, jfe, rlayout, blockIdx.x, gridDim.x,
+                                                                       tail, t_static);
 }
 
 // the launch of fields in registers with a dynamic walk (see fe_common.h)

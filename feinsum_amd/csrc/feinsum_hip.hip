@@ -253,8 +253,22 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
 #else
     (void)dbg;
 #endif
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
-                       dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
+    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+    if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
+        const int64_t t_static = tail_static_tiles(nTiles, (int64_t)grid * G::WAVES);
+        unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+        if (tail) {
+            static PerDeviceOnce once_tail;
+            if (int rc = configured(once_tail, fe::grad_w8_tail_kernel<56>, "grad p5 (components, A in LDS), dynamic walk", G::LDS_BYTES,
+                                    G::THREADS, G::BLOCKS_PER_CU))
+                return rc;
+            hipLaunchKernelGGL((fe::grad_w8_tail_kernel<56>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail,
+                               t_static);
+            return FE_OK;
+        }
+    }
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 4, 3, true, true>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr,
+                       P, nb, E, nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -293,8 +307,9 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
     });
     if (attr_rc != FE_OK) return attr_rc;
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>), dim3((unsigned)(blocks < cap ? blocks : cap)),
-                       dim3(256), G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
+    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr, P, nb, E,
+                       nTiles, opT, 0);
     return FE_OK;
 }
 
@@ -593,6 +608,19 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
         if (prep) {
             hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, false, false, true>), dim3((unsigned)blocks),
                                dim3(G::THREADS), G::LDS_BYTES, s, J, R, prep, P, E, nTiles, jfe, rifj);
+            return FE_OK;
+        }
+    }
+    if constexpr (NP == 56 && NFP == 21 && M == 1 && NF == fe::kFmNf && ALDS && NB == 4) {
+        const int64_t t_static = tail_static_tiles(nTiles, blocks * G::WAVES);
+        unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+        if (tail) {
+            static PerDeviceOnce once_tail;
+            snprintf(what, sizeof(what), "face-mass Np=56 b=%d (A in LDS), dynamic walk", NB);
+            if (int rc = configured(once_tail, fe::facemass_w8_tail_kernel<NP, NFP, NB>, what, G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
+                return rc;
+            hipLaunchKernelGGL((fe::facemass_w8_tail_kernel<NP, NFP, NB>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s, J, R, P,
+                               E, nTiles, jfe, rifj, tail, t_static);
             return FE_OK;
         }
     }

@@ -3,7 +3,7 @@
 A/B in one process: the persistent walk with a static tail (rounds < 0) against dynamic tails of 1 ... 12 rounds
 (fe_set_tail_rounds), on the SAME arrays -- outputs from the split allocator and from torch allocations.
 
-    python tools/tail_ab.py [grad|div|facemass] [E=1000000] [rounds="-1 1 2 3 6 12"]
+    python tools/tail_ab.py [grad|div|facemass|grad5|div5|facemass5] [E=1000000] [rounds="-1 1 2 3 6 12"]
 """
 import sys
 from pathlib import Path
@@ -19,8 +19,10 @@ from feinsum_amd import _hip, measure, placement  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "grad"
 E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 rounds = [int(r) for r in (sys.argv[3] if len(sys.argv) > 3 else "-1 1 2 3 6 12").split()]
-expr = {"grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4)}[what]()
+expr = {"grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4), "grad5": lambda: dg.grad(56), "div5": lambda: dg.div(56),
+        "facemass5": lambda: dg.face_mass(4, Np=56, Nfp=21)}[what]()
 nbytes = measure._get_footprint_gbytes(expr, E) * 1e9
+flops = f.count_ops(expr, long_dim_length=E)
 host = measure.generate_host_input_arrays(expr, E, np_seed=0)
 dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
 
@@ -41,7 +43,7 @@ for label, split in (("split allocator", True), ("torch allocations", False)):
         for r in rounds:
             _hip.set_tail_rounds(r)
             t = timed(bound, q, n)
-            cells.append(f"{r:4d}: {t * 1e6:7.2f} us ({nbytes / t / 8e12 * 100:4.1f} %)")
+            cells.append(f"{r:4d}: {t * 1e6:7.2f} us ({nbytes / t / 8e12 * 100:4.1f} % of HBM, {flops / t * 1e-12:5.1f} TFLOP/s)")
         print(f"{what} E={E} {label}: " + "  ".join(cells), flush=True)
     _hip.set_tail_rounds(-1)
     f.evaluate(expr, 0, dev, out_dict=outs, wait=True)
