@@ -33,6 +33,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -504,7 +505,7 @@ def main() -> None:
     import torch
 
     import feinsum_amd as f
-    from feinsum_amd import measure, operator, parallel
+    from feinsum_amd import _hip, measure, operator, parallel
 
     info = parallel.init_distributed()
     if info.world_size != args.gpus:
@@ -535,6 +536,12 @@ def main() -> None:
         """One allocation per array: inputs from torch, outputs from torch (what round 1 measured) or, *split*, from
         the split allocator."""
         stages, out_dicts, shared = [], [], {}
+        if split:   # the outputs of all stages are allocated one after the other: tell the allocator what is coming
+            from feinsum_amd import placement as _placement
+
+            total = sum(8 * len(expr.output_names) * math.prod(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+                        for expr in exprs)
+            _placement.split_reserve(total, device)
         for k, expr in enumerate(exprs):
             dev = _device_inputs(expr, E, device, seed=1000 * info.rank + k)
             for name in ("J", "R"):          # div and grad of one operator share J and D
@@ -677,6 +684,20 @@ def main() -> None:
         separate_ms = sb(args.steps) / args.steps * 1e3
         del op_sep, sb
 
+    # A/B outside the timed region: the same launch on the same operands with the STATIC walk (the timed launches hand their
+    # tiles to the waves by tickets behind two static rounds: feinsum_amd/csrc/fe_common.h, dynamic walk)
+    static_walk_ms = None
+    rounds_setting = _hip.set_tail_rounds(-1)
+    try:
+        if not args.no_protocol:
+            step_batch(max(args.warmup, 10))
+            static_walk_ms = step_batch(args.steps) / args.steps * 1e3
+    finally:
+        _hip.set_tail_rounds(rounds_setting)
+    walk_report = {"mode": "static" if rounds_setting < 0 else "tickets behind two static rounds (launches of five or more rounds)",
+                   "dynamic_rounds": "all" if rounds_setting >= (1 << 20) else rounds_setting,
+                   "kernel_ms_static_walk": None if static_walk_ms is None else round(static_walk_ms, 5)}
+
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
 
@@ -721,6 +742,7 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
+                 "walk": walk_report,
                  "dist_backend": info.backend if parallel.in_group() else None, "field_allgather": field_gather,
                  # how many ranks the process group really holds (1 without a group), and who started them
                  "ranks_seen": ranks_seen,

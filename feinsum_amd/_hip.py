@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
-    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
+    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -156,6 +156,8 @@ def load_library() -> C.CDLL:
     lib.fe_split_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.fe_split_stats.restype = C.c_int
     lib.fe_split_stats.argtypes = [C.c_char_p, C.c_size_t]
+    lib.fe_split_reserve.restype = C.c_int
+    lib.fe_split_reserve.argtypes = [C.c_size_t]
     lib.fe_split_trim.restype = C.c_int
     lib.fe_split_trim.argtypes = []
     lib.fe_set_tail_rounds.restype = C.c_int
@@ -355,6 +357,10 @@ def split_info(ptr: int) -> dict:
 def split_stats() -> dict:
     """The current device's pool of the split allocator."""
     return _json_call(load_library().fe_split_stats)
+
+
+def split_reserve(nbytes: int) -> None:
+    check(load_library().fe_split_reserve(C.c_size_t(int(nbytes))))
 
 
 def split_trim() -> None:

@@ -87,6 +87,7 @@ constexpr int kSplitProbePasses = 2;                // the probe writes 2 stream
 constexpr double kSplitSameBelowGBps = 5950.0;
 constexpr double kSplitOtherAboveGBps = 6400.0;
 constexpr size_t kSplitSpacerUnit = 32 * kSplitMiB;   // see acquire()
+constexpr size_t kSplitMinCollect = 128;               // pieces (512 MiB) of a run's class collected before the search skips ahead: see acquire()
 constexpr size_t kSplitAnchorBytes = 256 * kSplitMiB; // a class's reference region: ONE handle (one buddy block: pure)
 constexpr int kSplitMaxClasses = 3;                 // three superclasses on MI355X (a fourth "class" would be a misreading)
 
@@ -179,6 +180,7 @@ class SplitPool {
             if (orientation_++ & 1) std::swap(cls[0], cls[1]);
         }
         if (int rc = fresh_range(a.va_bytes, &a.va)) return rc;
+        reserve_pieces_ -= std::min(reserve_pieces_, (n_full + 1) / 2);
         for (size_t q = 0; q < n_full; ++q) {
             const int c = cls[q & 1];
             SplitPiece p = free_[c].back();
@@ -264,12 +266,27 @@ class SplitPool {
                         kSplitGroupBytes / kSplitMiB, va_reserved_, last_probes_.c_str());
     }
 
+    // The caller is about to allocate arrays of `bytes` bytes in all: collect half of that of each of two classes NOW, while
+    // the walk through the driver's memory is still inside the first class (arrays allocated one by one otherwise each take
+    // what they need, and the class the walk has left does not come back).  Allocates nothing that stays: the pieces wait in
+    // the pool (beyond its usual cap until they are handed out).
+    int reserve(size_t bytes) {
+        if (int rc = ensure_ready()) return rc;
+        const double t0 = split_now_ms();
+        reserve_pieces_ = (bytes / kSplitPiece + 1) / 2 + 1;
+        int ca = -1, cb = -1;
+        const int rc = acquire(reserve_pieces_, &ca, &cb);
+        alloc_ms_total_ += split_now_ms() - t0;
+        return rc;
+    }
+
     int trim() {   // give the free pieces back to the driver
         for (auto& list : free_) {
             for (auto& p : list) (void)hipMemRelease(p.handle);
             list.clear();
         }
         walk_gave_up_ = false;
+        reserve_pieces_ = 0;
         return FE_OK;
     }
 
@@ -295,6 +312,7 @@ class SplitPool {
     unsigned orientation_ = 0;
     int last_cls_ = 0;                 // class of the group created last (the driver hands out long runs of one class)
     bool walk_gave_up_ = false;        // a search for a second class ran out of budget: not repeated until fe_split_trim
+    size_t reserve_pieces_ = 0;        // pieces per class announced by reserve() and not handed out yet
     std::string last_probes_;
 
     void launch_probe(char* a, char* b) {
@@ -494,7 +512,8 @@ class SplitPool {
             if (c1 >= 0 && c2 >= 0 && free_[c2].size() >= need) { *a = c1; *b = c2; return true; }
             return false;
         };
-        const size_t need_groups = (need + kSplitGroup - 1) / kSplitGroup;
+        const size_t collect = std::max(kSplitMinCollect, reserve_pieces_);   // of the current run's class, before skipping
+        const size_t need_groups = (std::max(need, collect) + kSplitGroup - 1) / kSplitGroup;
         const size_t max_new = walk_gave_up_ ? 2 * need_groups + 2 : 8 * need_groups + 64;   // groups obtained in this call at most
         size_t made = 0, run = 0;
         int rc = FE_OK;
@@ -502,7 +521,11 @@ class SplitPool {
         while (!pick(ca, cb) && made < max_new) {
             // the driver hands out long runs of one class: with enough of the current run's class in the pool, skip
             // ahead with an unmapped spacer (doubling, 1 ... 16 GiB) before the next group
-            if (free_[last_cls_].size() >= need && run >= 3) {
+            // (not before the pool holds 512 MiB of the current run's class, or what fe_split_reserve announced: the arrays of a
+            // workload are allocated one after the other, and a class the walk has left behind does not come back -- the
+            // pipeline's four lift outputs were left unsplit because grad's output had taken all of the first class that the
+            // walk had collected: profiles/r03/bench_pipeline_walk_gave_up.json)
+            if (free_[last_cls_].size() >= std::max(need, collect) && run >= 3) {
                 if (spacer_bytes >= spacer_budget) break;   // nowhere left to search
                 if (spacer_ms_ - spacer_ms_at_start > search_ms_budget_) break;   // the driver is clearing what is skipped: enough
                 if (spacer_bytes + next_spacer > spacer_budget) next_spacer = (spacer_budget - spacer_bytes) / kSplitGran * kSplitGran;
@@ -544,7 +567,7 @@ class SplitPool {
         for (auto& h : discarded_) (void)hipMemRelease(h);
         discarded_.clear();
         for (auto& list : free_)   // what a long search collected of the class it did not need goes back to the driver
-            while (list.size() > std::max(max_pooled_pieces_ / 2, need)) {
+            while (list.size() > std::max(max_pooled_pieces_ / 2, std::max(need, reserve_pieces_))) {
                 (void)hipMemRelease(list.back().handle);
                 list.pop_back();
             }

@@ -1065,6 +1065,12 @@ int fe_split_stats(char* buf, size_t buf_len) {
     return pool->stats(buf, buf_len);
 }
 
+int fe_split_reserve(size_t bytes) {
+    SplitPool* pool = split_pool_of_current_device();
+    std::lock_guard<std::mutex> lock(pool->mu);
+    return pool->reserve(bytes);
+}
+
 int fe_split_trim(void) {
     SplitPool* pool = split_pool_of_current_device();
     std::lock_guard<std::mutex> lock(pool->mu);

@@ -190,6 +190,12 @@ def generate_out_arrays(cq: Any, einsum: BatchedEinsum, long_dim_length: int, *,
     q = _as_queue(cq)
     shape = _concrete_shape(einsum.shape, long_dim_length)
     outs = {}
+    if split and len(einsum.output_names) > 1:   # several arrays, allocated one after the other: say what is coming
+        from feinsum_amd import placement
+
+        nbytes = sum(int(np.prod(shape)) * result_dtype(einsum, k).itemsize for k in range(len(einsum.output_names)))
+        if nbytes >= placement.SPLIT_MIN_BYTES:
+            placement.split_reserve(nbytes, q.torch_device)
     for k, name in enumerate(einsum.output_names):
         tdtype = getattr(torch, result_dtype(einsum, k).name)
         if split:

@@ -124,6 +124,18 @@ def split_stats(device: Any = None) -> Dict[str, Any]:
         return _hip.split_stats()
 
 
+def split_reserve(nbytes: int, device: Any = None) -> None:
+    """Announce the total size of the written arrays about to be allocated with :func:`empty` / :func:`zeros` on *device*
+    (``fe_split_reserve``): the allocator collects half of it of each of two classes of physical memory at once, instead
+    of array by array -- a class its search has left behind does not come back."""
+    import torch
+
+    from feinsum_amd import _hip
+
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _hip.split_reserve(int(nbytes))
+
+
 def split_trim(device: Any = None) -> None:
     """Release the allocator's free pieces on *device* to the driver."""
     import torch

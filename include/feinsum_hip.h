@@ -321,12 +321,17 @@ int fe_kernel_resources(char* buf, size_t buf_len);
  *   fe_split_stats  JSON about the current device's pool: classes seen, free pieces per class, pieces created, groups
  *                   probed, spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_arrays" counts
  *                   arrays that had to take all pieces from one class (no second class found within the budget)
+ *   fe_split_reserve announces the total size of the arrays about to be allocated: half of it is collected of each of two
+ *                   classes at once, while the search through the driver's memory is still inside the first class (arrays
+ *                   allocated one by one otherwise take only what each needs -- at least 512 MiB per class are collected
+ *                   anyway -- and a class the search has left does not come back); allocates nothing that stays
  *   fe_split_trim   releases the pool's free pieces to the driver
  * Both JSON calls return the length written (>= 0) or a negative error code. */
 int fe_split_alloc(void** ptr, size_t bytes, int32_t flags);
 int fe_split_free(void* ptr);
 int fe_split_info(const void* ptr, char* buf, size_t buf_len);
 int fe_split_stats(char* buf, size_t buf_len);
+int fe_split_reserve(size_t bytes);
 int fe_split_trim(void);
 
 /* Algorithmic flops per element for a family (numerator of GFLOP/s; same
