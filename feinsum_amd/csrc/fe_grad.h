@@ -206,7 +206,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     const GradFields& P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx_, int64_t E,
     int64_t nTiles, int opT, const unsigned bid, const unsigned nblk, unsigned* __restrict__ tail = nullptr,
     int64_t t_static = 0) {
-    static_assert(!kDyn || (kPlain && M == 1 && !kPrep), "dynamic tail: plain launches of one field, one sub-tile per tile");
+    static_assert(!kDyn || (kPlain && !kPrep), "dynamic walk: plain launches of one field");
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -514,11 +514,11 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
 }
 
 // the plain single-field launch with a dynamic tail (see fe_common.h)
-template <int NP, int kDbg = 0>
+template <int NP, int M = 1, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void grad3d_mfma_tail_kernel(
     GradFields P, const double* __restrict__ D, int64_t E, int64_t nTiles, int opT, unsigned* __restrict__ tail,
     int64_t t_static) {
-    grad3d_mfma_body<NP, 1, kDbg, true, false, true>(P, D, nullptr, 1, 3, E, nTiles, opT, blockIdx.x, gridDim.x, tail, t_static);
+    grad3d_mfma_body<NP, M, kDbg, true, false, true>(P, D, nullptr, 1, 3, E, nTiles, opT, blockIdx.x, gridDim.x, tail, t_static);
 }
 
 // The grad section of a prepared operator: fragment f = t * KS + ks of lane (g, n) is

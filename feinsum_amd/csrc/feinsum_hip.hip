@@ -438,15 +438,15 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                                    E, nTiles, opT);
                 break;
             }
-            if constexpr (NP == 35 && M == 1) {
-                if (nb == 1) {   // the last rounds of the walk by tickets (fe_common.h: dynamic tail)
+            {
+                if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h: dynamic walk)
                     const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
-                        if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP>, "grad Np=35 M=1, dynamic walk", G::LDS_BYTES, 256, 2))
-                            return rc;
-                        hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
+                        snprintf(what, sizeof(what), "grad Np=%d M=%d, dynamic walk", NP, M);
+                        if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, 2)) return rc;
+                        hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
                         break;
                     }
                 }
@@ -505,15 +505,14 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                                    prep, P, nb, E, nTiles, opT, 0);
                 break;
             }
-            if constexpr (NP == 35) {
+            {
                 if (nb == 1 && !(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h)
                     const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
-                        if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, "div Np=35, dynamic walk", G::LDS_BYTES, 256,
-                                                G::BLOCKS_PER_CU))
-                            return rc;
+                        snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
+                        if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
                         hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, E, nTiles, opT, tail, t_static);
                         break;
                     }
@@ -624,13 +623,13 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
             return FE_OK;
         }
     }
-    if constexpr (NP == 35 && NFP == 15 && M == 1 && NF == fe::kFmNf && !ALDS && (NB == 3 || NB == 4)) {
+    if constexpr (NF == fe::kFmNf && !ALDS && (NB == 3 || NB == 4)) {   // tetrahedra p = 1 .. 4
         // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
         const int64_t t_static = tail_static_tiles(nTiles, blocks * G::WAVES);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
-            snprintf(what, sizeof(what), "face-mass Np=35 b=%d, dynamic walk", NB);
+            snprintf(what, sizeof(what), "face-mass Np=%d M=%d b=%d, dynamic walk", NP, M, NB);
             if (int rc = configured(once_tail, fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>, what, G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
                 return rc;
             hipLaunchKernelGGL((fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s,

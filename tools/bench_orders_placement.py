@@ -1,5 +1,6 @@
 """MFMA kernels of all tetrahedral orders: every array from torch ("separate") against outputs from the split allocator
-("split", timeit's default; pass "tuned" as a second argument to add round 2's arena scan).
+("split", timeit's default; pass "tuned" as a second argument to add round 2's arena scan), and the split placement once more
+with the static walk (fe_set_tail_rounds(-1)).
 
     python tools/bench_orders_placement.py [E] [tuned]
 """
@@ -11,6 +12,7 @@ import numpy as np  # noqa: E402
 
 import dg  # noqa: E402
 import feinsum_amd as f  # noqa: E402
+from feinsum_amd import _hip  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
@@ -22,4 +24,8 @@ for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
         for what, tr in ((m, {"variant": "mfma", "placement": m}) for m in modes):
             r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
             row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")
+        _hip.set_tail_rounds(-1)
+        r = f.timeit_details(expr, cq=0, transform={"variant": "mfma", "placement": "split"}, long_dim_length=E, min_secs=0.5)
+        _hip.set_tail_rounds(1 << 20)
+        row.append(f"split, static walk {r.seconds_device * 1e3:7.4f} ms ({gops / r.seconds_device / roof * 100:4.1f} %)")
         print(f"Np = {Np:2d} {name:14s} " + " | ".join(row), flush=True)
