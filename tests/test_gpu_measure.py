@@ -294,3 +294,44 @@ def test_launchers_are_graph_capturable():
         for name, row in zip(e.output_names, e.args):
             ref = np_oracle.reference_outputs(e.get_subscripts(), [[h[a.name] for a in row]])[0]
             assert np_oracle.max_rel_err(o[name].cpu().numpy(), ref) <= 1e-12
+
+
+def test_dynamic_walk_launches_replay_in_a_graph():
+    """Launches whose tiles come by tickets (five or more rounds: feinsum_amd/csrc/fe_common.h, dynamic walk) captured into a
+    HIP graph and replayed several times: a launch leaves its ticket counters zeroed, so a replay -- same kernel arguments,
+    same counters -- hands out every tile again.  Bitwise the static walk's results for the inputs of each replay."""
+    import torch
+
+    from feinsum_amd import _hip
+
+    exprs = [dg.div(), dg.grad(), dg.face_mass(4)]
+    E = 200_003
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    devs = [{a: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in e.arg_to_shape[a]), dtype=torch.float64,
+                           device="cuda", generator=gen) for a in sorted(e.all_args)} for e in exprs]
+    outs = [measure.generate_out_arrays(0, e, E) for e in exprs]
+    for e, d, o in zip(exprs, devs, outs):          # warm-up outside capture (attribute setup, the ticket buffer)
+        f.evaluate(e, 0, d, out_dict=o)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        for e, d, o in zip(exprs, devs, outs):
+            f.evaluate(e, f.DeviceQueue(0, stream=torch.cuda.current_stream()), d, out_dict=o)
+    for replay in range(3):
+        for d in devs:
+            for t in d.values():
+                t.uniform_(0.0, 1.0, generator=gen)
+        for o in outs:
+            for t in o.values():
+                t.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        before = _hip.set_tail_rounds(-1)
+        try:
+            for e, d, o in zip(exprs, devs, outs):
+                static = f.evaluate(e, 0, d, wait=True)
+                for name in static:
+                    assert torch.equal(static[name], o[name]), (replay, e.get_subscripts(), name)
+        finally:
+            _hip.set_tail_rounds(before)
