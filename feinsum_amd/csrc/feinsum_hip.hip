@@ -152,7 +152,7 @@ unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 25
 constexpr int kTailSlots = 64;
 struct TailBuffers {
     std::mutex lock;
-    unsigned* base[64] = {};
+    std::atomic<unsigned*> base[64];   // (static storage: null)
     bool failed[64] = {};
     std::atomic<unsigned> next[64];
 };
@@ -160,9 +160,9 @@ TailBuffers g_tail;
 unsigned* tail_slot(hipStream_t s, int sets = 1) {   // `sets` consecutive counter sets (fused launches: one per body)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!g_tail.base[dev]) {
+    if (!g_tail.base[dev].load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> guard(g_tail.lock);
-        if (!g_tail.base[dev] && !g_tail.failed[dev]) {
+        if (!g_tail.base[dev].load(std::memory_order_relaxed) && !g_tail.failed[dev]) {
             hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
                 (void)hipGetLastError();
@@ -175,13 +175,14 @@ unsigned* tail_slot(hipStream_t s, int sets = 1) {   // `sets` consecutive count
                 g_tail.failed[dev] = true;
                 return nullptr;
             }
-            g_tail.base[dev] = p;
+            g_tail.base[dev].store(p, std::memory_order_release);
         }
     }
-    if (!g_tail.base[dev] || sets < 1 || sets > 4) return nullptr;
+    unsigned* const base = g_tail.base[dev].load(std::memory_order_acquire);
+    if (!base || sets < 1 || sets > 4) return nullptr;
     // slots are handed out in groups of four, so that a launch with up to four counter sets has them side by side
     const unsigned group = g_tail.next[dev].fetch_add(1) % (kTailSlots / 4);
-    return g_tail.base[dev] + (size_t)group * 4 * fe::kTailWords;
+    return base + (size_t)group * 4 * fe::kTailWords;
 }
 // Number of statically walked tiles of a launch of `waves` waves: two rounds, the rest by tickets (FEINSUM_TAIL_ROUNDS /
 // fe_set_tail_rounds: at most so many full rounds by tickets; negative: none); launches of fewer than five rounds walk
