@@ -191,7 +191,7 @@ std::atomic<int> g_tail_rounds{[] { const char* e = getenv("FEINSUM_TAIL_ROUNDS"
 int64_t tail_static_tiles(int64_t nTiles, int64_t waves) {
     const int dyn_rounds = g_tail_rounds.load(std::memory_order_relaxed);
     const int64_t rounds = nTiles / waves;
-    if (dyn_rounds < 0 || rounds < 5) return nTiles;
+    if (dyn_rounds < 0 || rounds < 5 || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
     int64_t ks = rounds - dyn_rounds;
     if (ks < 2) ks = 2;
     return ks * waves;
