@@ -101,9 +101,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // tiles per us).  What works (profiles/r03/dynamic_walk_*.txt: grad E = 1e6 77.8 -> 80.6 % of the roofline, 69.2 -> 76.4 %
 // with every array from torch):
 //  * every wave walks `t_static / waves` rounds (two) statically, so that the first ticket's latency hides behind a tile;
-//  * the tiles [t_static, nTiles) are dealt out by kTailPools counters: pool p holds the tiles t_static + p + kTailPools * t,
-//    and a block's pool is (bid / 8) % kTailPools, so that every pool is drained by waves of all eight XCDs and empties at the
-//    machine's average pace (no stealing needed); 4 pools are too few (75.5 %), 8 and 16 measure alike;
+//  * the tiles [t_static, nTiles) are dealt out by kTailPools counters: ticket t of pool p is the tile
+//    t_static + kTailPools * t + (p + t) mod kTailPools, and a block's pool is (bid / 8) % kTailPools, so that every pool is
+//    drained by waves of all eight XCDs (no stealing needed); 4 pools are too few (75.5 %), 8 and 16 measure alike.  The
+//    residue ROTATES with t because tiles are not equally fast: with the fixed residue p the pools 3, 7, 11, 15 -- the tiles
+//    = 3 mod 4 -- took 3 % longer per tile and ended 6 - 10 us behind the others, whatever the spacing of the counters
+//    (per-wave time stamps: profiles/r03/dynamic_walk_stamps.txt);
 //  * one returning atomic per tile, requested ONE TILE AHEAD -- at the top of the iteration that prefetches the tile before
 //    -- so that its latency never shows;
 //  * the wave whose ticket comes back beyond the pool stops asking and reports to the pool's second counter; the last of the
@@ -159,7 +162,7 @@ __device__ __forceinline__ unsigned tail_wait() {
 // s_cselect_b32 (SCC, left over from the address addition) -- every ticket of the face-mass kernel read as "beyond the pool".
 __device__ __forceinline__ int64_t tail_ticket_tile(unsigned t, int64_t t_static, int pool, int64_t n_tiles) {
     const unsigned room = (unsigned)(n_tiles - t_static);          // dynamic tiles
-    const unsigned off = t * (unsigned)kTailPools + (unsigned)pool;
+    const unsigned off = t * (unsigned)kTailPools + (((unsigned)pool + t) & (unsigned)(kTailPools - 1));   // (the pool's residue rotates: see above)
     const bool ok = t < (1u << 26) && off < room;
     return ok ? t_static + (int64_t)off : (int64_t)-1;
 }

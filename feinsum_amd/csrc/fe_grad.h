@@ -374,6 +374,22 @@ __device__ __forceinline__ void grad3d_mfma_body(
         }
     };
 
+#ifdef FE_EXPERIMENTS
+    unsigned long long c0 = 0, r0 = 0;
+    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    auto write_stamps = [&](int tiles_done) {
+        if (!((kDbg & 32) && lane == 0)) return;
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        const int w = bid * G::WAVES + wave;
+        if (w < 4096) {
+            fe_dbg_stamps[w][0] = t_entry; fe_dbg_stamps[w][1] = r0; fe_dbg_stamps[w][2] = t_end;
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+            fe_dbg_stamps[w][3] = xcc | ((unsigned long long)hw << 8) | ((unsigned long long)tiles_done << 40);
+        }
+        if (w == 0) { fe_dbg_clock[0] = __builtin_amdgcn_s_memtime() - c0; fe_dbg_clock[1] = t_end - r0; }
+    };
+#endif
     if constexpr (kDyn) {
         if (dyn) {
             // ---- walk with a dynamic tail (fe_common.h): static tiles first + k stride below t_static, then tickets.
@@ -446,16 +462,15 @@ __device__ __forceinline__ void grad3d_mfma_body(
                     __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+#ifdef FE_EXPERIMENTS
+            write_stamps(iteration);
+#endif
             return;
         }
     }
 
     int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
-#ifdef FE_EXPERIMENTS
-    unsigned long long c0 = 0, r0 = 0;
-    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
     const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
     while (tile < tEnd) {
@@ -492,17 +507,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
         if (next_new_tile) jbuf ^= 1;
     }
 #ifdef FE_EXPERIMENTS
-    if ((kDbg & 32) && lane == 0) {
-        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-        const int w = bid * G::WAVES + wave;
-        if (w < 4096) {
-            fe_dbg_stamps[w][0] = t_entry; fe_dbg_stamps[w][1] = r0; fe_dbg_stamps[w][2] = t_end;
-            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
-            fe_dbg_stamps[w][3] = xcc | ((unsigned long long)hw << 8);
-        }
-        if (w == 0) { fe_dbg_clock[0] = __builtin_amdgcn_s_memtime() - c0; fe_dbg_clock[1] = t_end - r0; }
-    }
+    write_stamps(iteration);
 #endif
 }
 

@@ -424,10 +424,22 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
         case 1: FE_GRAD_CASE(1); break;
         case 2: FE_GRAD_CASE(2); break;
         case 32:
-            if (gsec)
+            if (gsec) {
                 hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
                                    E, nTiles, opT);
-            else FE_GRAD_CASE(32);
+                break;
+            }
+            if (nb == 1) {   // per-wave time stamps of the dynamic walk
+                const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+                if (tail) {
+                    static PerDeviceOnce once_stamps;
+                    once_stamps.run([] { return configure_kernel(fe::grad3d_mfma_tail_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1); });
+                    hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 32>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
+                    break;
+                }
+            }
+            FE_GRAD_CASE(32);
             break;
         case 64: FE_GRAD_CASE(64); break;
         case 96: FE_GRAD_CASE(96); break;

@@ -121,10 +121,11 @@ static int ab_main(int argc, char** argv) {
                     FILE* f = fopen(getenv("FE_DUMP_STAMPS"), "w");
                     unsigned long long tmin = ~0ull;
                     for (int w = 0; w < 2048; ++w) tmin = std::min(tmin, st4[4 * w]);
-                    fprintf(f, "wave,xcc,hw_id,entry_us,loop_start_us,loop_end_us\n");
+                    fprintf(f, "wave,xcc,hw_id,entry_us,loop_start_us,loop_end_us,tiles\n");
                     for (int w = 0; w < 2048; ++w)
-                        fprintf(f, "%d,%llu,%llu,%.2f,%.2f,%.2f\n", w, st4[4 * w + 3] & 0xff, st4[4 * w + 3] >> 8,
-                                (st4[4 * w] - tmin) / 100.0, (st4[4 * w + 1] - tmin) / 100.0, (st4[4 * w + 2] - tmin) / 100.0);
+                        fprintf(f, "%d,%llu,%llu,%.2f,%.2f,%.2f,%llu\n", w, st4[4 * w + 3] & 0xff, (st4[4 * w + 3] >> 8) & 0xffffffffull,
+                                (st4[4 * w] - tmin) / 100.0, (st4[4 * w + 1] - tmin) / 100.0, (st4[4 * w + 2] - tmin) / 100.0,
+                                st4[4 * w + 3] >> 40);
                     fclose(f);
                 }
                 unsigned long long t0 = ~0ull, e_max = 0, l_min = ~0ull, l_max = 0, end_min = ~0ull, end_max = 0;
