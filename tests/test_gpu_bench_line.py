@@ -68,6 +68,7 @@ def test_bench_default_and_tuned_placements(workload, placement):
     line = _json_line(out.stdout)
     assert line["placement"]["mode"] == placement and line["result_finite"] and line["value"] > 0
     assert line["kernel_ms_separate_allocations"] > 0            # the A/B against torch allocations stays in the line
+    assert line["walk"]["kernel_ms_static_walk"] > 0 and line["walk"]["dynamic_rounds"] == "all"   # ... and the A/B of the walks
     assert line["config"]["variant"] == "auto"                   # no silent switch of the kernel variant
     if placement == "split":
         rep = line["placement"]
