@@ -144,7 +144,51 @@ def run_einsum(n_cases: int, seed: int) -> int:
     return failures
 
 
+def run_dynamic_walk(n_cases: int, seed: int) -> int:
+    """Launches large enough for the dynamic walk (five or more rounds of tiles: fe_common.h) -- single launches of all
+    tetrahedral orders and fused operators at random element counts: tickets against the static walk, bitwise, and the
+    ticket launch a second time (its counters must have been left zeroed)."""
+    from feinsum_amd import _hip
+
+    rng.seed(seed)
+    failures = 0
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        for case in range(n_cases):
+            Np, Nfp = rng.choice(ORDERS3[:5])
+            E = rng.randrange(170_000 if Np >= 20 else 900_000, 700_000 if Np >= 20 else 1_300_000)
+            kind = rng.choice(["grad", "div", "fm3", "fm4", "operator"])
+            if kind == "operator":
+                exprs = [dg.div(Np), dg.grad(Np), dg.face_mass(rng.choice([2, 3, 4]), Np=Np, Nfp=Nfp)]
+            else:
+                exprs = [{"grad": lambda: dg.grad(Np), "div": lambda: dg.div(Np), "fm3": lambda: dg.face_mass(3, Np=Np, Nfp=Nfp),
+                          "fm4": lambda: dg.face_mass(4, Np=Np, Nfp=Nfp)}[kind]()]
+            gen = torch.Generator(device="cuda").manual_seed(case)
+            devs = [{a: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in e.arg_to_shape[a]), dtype=torch.float64,
+                                   device="cuda", generator=gen) for a in sorted(e.all_args)} for e in exprs]
+            if len(exprs) == 3:
+                devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+
+            def evaluate():
+                if len(exprs) == 1:
+                    return [f.evaluate(exprs[0], 0, devs[0], wait=True)]
+                return f.evaluate_operator(list(zip(exprs, devs)), 0, wait=True)
+            _hip.set_tail_rounds(-1)
+            static = [{k: v.clone() for k, v in o.items()} for o in evaluate()]
+            _hip.set_tail_rounds(rng.choice([1 << 20, 1 << 20, 1, 4]))
+            for rep in range(2):
+                for o_static, o in zip(static, evaluate()):
+                    for k in o_static:
+                        if not torch.equal(o_static[k], o[k]):
+                            failures += 1
+                            print(f"FAIL dynamic walk case {case}: {kind} Np={Np} E={E} output {k} (launch {rep})", flush=True)
+    finally:
+        _hip.set_tail_rounds(before)
+    print(f"{n_cases} dynamic-walk cases, failures {failures}")
+    return failures
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    sys.exit(1 if run(n, seed) + run_operator(n // 4, seed) + run_einsum(n, seed) else 0)
+    sys.exit(1 if run(n, seed) + run_operator(n // 4, seed) + run_einsum(n, seed) + run_dynamic_walk(n // 5, seed) else 0)
