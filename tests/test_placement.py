@@ -1,5 +1,6 @@
 """feinsum_amd.placement: arena layout arithmetic (CPU) and the tuned layout on the device."""
 
+import numpy as np
 import pytest
 
 from feinsum_amd import placement
@@ -190,3 +191,29 @@ def test_split_allocator_never_hands_out_an_address_twice():
         assert float(t[0]) == cycle + 1 and float(t[-1]) == cycle + 1 and float(t.sum()) == (cycle + 1) * 40_000_000.0
         assert float(u[0]) == -(cycle + 1) and float(u[-1]) == -(cycle + 1)
         del t, u
+
+
+@pytest.mark.gpu
+def test_split_reserve_collects_both_classes_for_arrays_allocated_one_after_the_other():
+    """``placement.split_reserve(total)`` announces what is about to be allocated: afterwards the pool holds at least half of
+    that of each of two classes, and every one of the arrays allocated one after the other is split between the two (without
+    the announcement the first array could use up the first class the allocator's search had collected: bench.py's pipeline
+    once left its four lift outputs unsplit)."""
+    import torch
+
+    shapes = [(3, 1_000_000, 35), (1_000_000, 35)] + [(1_000_000, 35)] * 4        # the pipeline's outputs: 2.24 GB
+    total = sum(8 * int(np.prod(sh)) for sh in shapes)
+    placement.split_trim("cuda:0")
+    placement.split_reserve(total, "cuda:0")
+    pool = placement.split_stats("cuda:0")
+    free = sorted(pool["free_pieces"], reverse=True) if "free_pieces" in pool else None
+    arrays = [placement.empty(sh, torch.float64, "cuda:0") for sh in shapes]
+    for t in arrays:
+        info = placement.split_info(t)
+        by_class = sorted(info["pieces_by_class"], reverse=True)
+        assert by_class[0] > 0 and by_class[1] > 0 and abs(by_class[0] - by_class[1]) <= 1, info["pieces_by_class"]
+    after = placement.split_stats("cuda:0")
+    assert not after["walk_gave_up"] and after["unsplit_arrays"] == pool["unsplit_arrays"]
+    if free is not None:
+        assert free[1] * placement.split_info(arrays[0])["piece_mib"] * (1 << 20) >= total // 2 - (64 << 20)
+    del arrays
