@@ -626,10 +626,11 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
-    // dynamic walk (one field, plain walk): vector-memory ops of an iteration in issue order [ticket or report] L(next) S(this),
-    // so the counted wait at the top of a tile is that of the static walk; the ticket asked for in front of L(next) is read
-    // one iteration later at the same place
-    const bool dyn = kDyn && tail != nullptr && t_static < nTiles && nb == 1 && !split_walk;   // grid-uniform
+    // dynamic walk (plain walk): vector-memory ops of a unit in issue order [ticket or report] L(next unit) S(this unit), so the
+    // counted wait at the top of a unit is that of the static walk.  One field: the ticket asked for in front of L(next) is for
+    // the tile after next and is read one iteration later at the same place.  b fields (units (tile, field), field fastest):
+    // the ticket for the next tile is asked for with the tile's first field and read with its last, b - 1 units later.
+    const bool dyn = kDyn && tail != nullptr && t_static < nTiles && !split_walk;   // grid-uniform
     const int pool = (bid >> 3) & (kTailPools - 1);
     unsigned* const counter = tail + pool * kTailStride;
     unsigned* const done = counter + kTailStride / 2;
@@ -697,7 +698,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                 for (int k = 0; k < ND * ND; ++k) asm volatile("" : "+v"(jkeep[m][k]));
         }
         if constexpr (kDyn) {
-            if (dyn) {
+            if (dyn && nb == 1) {
                 if (pending) {   // asked for one iteration ago, in front of this tile's loads: it is here
                     const unsigned t = tail_wait<G::STORES, 0>();
                     nt = tail_ticket_tile(t, t_static, pool, tEnd);
@@ -714,6 +715,24 @@ __device__ __forceinline__ void div3d_mfma_body(
                     pending = true;
                 }
                 if (nt < 0) nt = tEnd;
+            } else if (dyn) {
+                if (fk == 0 && static_next(tile) < 0) {   // first field of a tile whose successor is not static
+                    tail_request<0>(counter);
+                    pending = true;
+                }
+                if (next_new_tile) {
+                    if (pending) {   // asked for b - 1 units ago, in front of the second field's loads, which this wave has waited for
+                        nt = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, pool, tEnd);
+                        pending = false;
+                        if (nt < 0) {
+                            tail_request<1>(done);
+                            reported = true;
+                        }
+                    } else {
+                        nt = static_next(tile);
+                    }
+                    if (nt < 0) nt = tEnd;
+                }
             }
         }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
@@ -858,9 +877,9 @@ __device__ __forceinline__ void div3d_mfma_body(
 // the plain single-field div with a dynamic walk (see fe_common.h)
 template <int NP, int M>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int64_t E, int64_t nTiles, int opT,
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
     unsigned* __restrict__ tail, int64_t t_static) {
-    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, 1, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
+    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
                                                                 tail, t_static);
 }
 

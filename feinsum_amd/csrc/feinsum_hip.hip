@@ -519,14 +519,14 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                 break;
             }
             {
-                if (nb == 1 && !(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h)
+                if (!(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h); any number of fields
                     const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
                         snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
                         if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
-                        hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, E, nTiles, opT, tail, t_static);
+                        hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
                         break;
                     }
                 }
