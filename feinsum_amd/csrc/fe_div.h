@@ -875,12 +875,13 @@ __device__ __forceinline__ void div3d_mfma_body(
 }
 
 // the plain single-field div with a dynamic walk (see fe_common.h)
-template <int NP, int M>
+// (kBatched: see grad3d_mfma_tail_kernel)
+template <int NP, int M, bool kBatched = false>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_kernel(
     const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
     unsigned* __restrict__ tail, int64_t t_static) {
-    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
-                                                                tail, t_static);
+    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, kBatched ? nb : 1, E, nTiles, opT, 0, blockIdx.x,
+                                                                gridDim.x, nullptr, tail, t_static);
 }
 
 // grad by components in eight-wave blocks (p = 5) with a dynamic walk (nb is a run-time argument although the launcher passes

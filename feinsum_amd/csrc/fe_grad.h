@@ -391,7 +391,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     };
 #endif
     if constexpr (kDyn) {
-        if (dyn) {
+        if (dyn && nb == 1) {
             // ---- walk with a dynamic tail (fe_common.h): static tiles first + k stride below t_static, then tickets.
             //      Vector-memory ops of an iteration in issue order: [A = ticket for the tile after next] L(next) S(cur);
             //      every wave has a static first tile (t_static >= number of waves).
@@ -473,14 +473,46 @@ __device__ __forceinline__ void grad3d_mfma_body(
     bool first = true;
     const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
+    // dynamic walk with b >= 2 fields (units (tile, field), field fastest): the ticket for the next tile is asked for at the top
+    // of the tile's first field -- in front of the next unit's loads -- and read at the top of its last field, where the wait
+    // for it (everything but the previous unit's stores) is the wait for this unit's loads as well
+    const bool dynb = kDyn && dyn && nb >= 2;   // grid-uniform
+    const int poolb = (bid >> 3) & (kTailPools - 1);
+    unsigned* const counterb = tail + poolb * kTailStride;
+    unsigned* const doneb = counterb + kTailStride / 2;
+    bool pendingb = false, reportedb = false;
     while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
-        // Vector-memory ops in issue order: L(unit) S(previous unit) L(next unit) | wait L(unit).
+        // Vector-memory ops in issue order: L(unit) S(previous unit) [ticket] L(next unit) | wait L(unit).
         // The stores of the previous unit and the loads of the next one are younger than this
         // unit's loads and stay in flight.
         const bool next_new_tile = (fk + 1 == nb);
-        const int64_t nt = next_new_tile ? tile + stride : tile;
+        int64_t nt = next_new_tile ? tile + stride : tile;
         const int nk = next_new_tile ? 0 : fk + 1;
+        bool extra = false;   // a ticket or the report goes out at this top
+        if constexpr (kDyn) {
+            if (dynb) {
+                const bool successor_static = tile < t_static && tile + stride < t_static;
+                if (next_new_tile) {
+                    if (pendingb) {
+                        nt = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, poolb, tEnd);
+                        pendingb = false;
+                        if (nt < 0) {   // this wave's pool is empty: stop asking, report
+                            tail_request<1>(doneb);
+                            reportedb = true;
+                            extra = true;
+                            nt = tEnd;
+                        }
+                    } else if (!successor_static) {
+                        nt = tEnd;   // (cannot happen: a tile whose successor is not static has asked at its first field)
+                    }
+                } else if (fk == 0 && !successor_static) {
+                    tail_request<0>(counterb);
+                    pendingb = true;
+                    extra = true;
+                }
+            }
+        }
         if (kDbg & 8) {
             wait_vmcnt<0>();
         } else if (nt < tEnd) {
@@ -489,12 +521,16 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
                 if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
                 else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
+            } else if (kDyn && extra) {
+                if (first) wait_vmcnt<G::U_INSTR + 1>();
+                else wait_vmcnt<G::U_INSTR + G::STORES + 1>();
             } else {
                 if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
                 else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
             }
         } else {
-            if (first || (kDbg & 2)) wait_vmcnt<0>();
+            if (kDyn && extra) wait_vmcnt<G::STORES + 1>();
+            else if (first || (kDbg & 2)) wait_vmcnt<0>();
             else wait_vmcnt_planes<0, G::PLANE_STORES>(nx);
         }
         first = false;
@@ -505,6 +541,16 @@ __device__ __forceinline__ void grad3d_mfma_body(
         tile = nt;
         ub ^= 1;
         if (next_new_tile) jbuf ^= 1;
+    }
+    if constexpr (kDyn) {
+        if (reportedb) {   // the last wave of a pool to report leaves the pool's counters zeroed (younger than the report: this unit's stores)
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * poolb));
+            const unsigned before = tail_wait<G::STORES, 1>();
+            if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                __hip_atomic_store(counterb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(doneb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 #ifdef FE_EXPERIMENTS
     write_stamps(iteration);
@@ -519,11 +565,14 @@ __global__ __launch_bounds__(256, 2) void grad3d_mfma_kernel(
 }
 
 // the plain single-field launch with a dynamic tail (see fe_common.h)
-template <int NP, int M = 1, int kDbg = 0>
+// kBatched: the number of fields is the run-time argument; else one field, known to the compiler (the single-field kernel
+// keeps the code it had before batched launches learned to walk dynamically)
+template <int NP, int M = 1, int kDbg = 0, bool kBatched = false>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void grad3d_mfma_tail_kernel(
-    GradFields P, const double* __restrict__ D, int64_t E, int64_t nTiles, int opT, unsigned* __restrict__ tail,
+    GradFields P, const double* __restrict__ D, int nb, int64_t E, int64_t nTiles, int opT, unsigned* __restrict__ tail,
     int64_t t_static) {
-    grad3d_mfma_body<NP, M, kDbg, true, false, true>(P, D, nullptr, 1, 3, E, nTiles, opT, blockIdx.x, gridDim.x, tail, t_static);
+    grad3d_mfma_body<NP, M, kDbg, true, false, true>(P, D, nullptr, kBatched ? nb : 1, 3, E, nTiles, opT, blockIdx.x, gridDim.x, tail,
+                                                     t_static);
 }
 
 // The grad section of a prepared operator: fragment f = t * KS + ks of lane (g, n) is

@@ -435,7 +435,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                 if (tail) {
                     static PerDeviceOnce once_stamps;
                     once_stamps.run([] { return configure_kernel(fe::grad3d_mfma_tail_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1); });
-                    hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 32>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
+                    hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 32>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
                     break;
                 }
             }
@@ -452,15 +452,25 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                 break;
             }
             {
-                if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h: dynamic walk)
+                {   // behind two static rounds the tiles come by tickets (fe_common.h: dynamic walk); any number of fields
                     const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
-                        snprintf(what, sizeof(what), "grad Np=%d M=%d, dynamic walk", NP, M);
-                        if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, 2)) return rc;
-                        hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, E, nTiles, opT, tail, t_static);
-                        break;
+                        if (nb == 1) {
+                            snprintf(what, sizeof(what), "grad Np=%d M=%d, dynamic walk", NP, M);
+                            if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, 2)) return rc;
+                            hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
+                            break;
+                        }
+                        if constexpr (NP == 35) {   // b fields (the batched launches of the other orders walk statically)
+                            static PerDeviceOnce once_tail_b;
+                            snprintf(what, sizeof(what), "grad Np=%d M=%d x b, dynamic walk", NP, M);
+                            if (int rc = configured(once_tail_b, fe::grad3d_mfma_tail_kernel<NP, M, 0, true>, what, G::LDS_BYTES, 256, 2)) return rc;
+                            hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 0, true>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail,
+                                               t_static);
+                            break;
+                        }
                     }
                 }
             }
@@ -524,10 +534,21 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
-                        snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
-                        if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
-                        hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
-                        break;
+                        if (nb == 1) {
+                            snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
+                            if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                            hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
+                            break;
+                        }
+                        if constexpr (NP == 35) {   // b fields (the batched launches of the other orders walk statically)
+                            static PerDeviceOnce once_tail_b;
+                            snprintf(what, sizeof(what), "div Np=%d M=%d x b, dynamic walk", NP, M);
+                            if (int rc = configured(once_tail_b, fe::div3d_mfma_tail_kernel<NP, M, true>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU))
+                                return rc;
+                            hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M, true>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail,
+                                               t_static);
+                            break;
+                        }
                     }
                 }
             }

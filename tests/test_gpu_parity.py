@@ -778,7 +778,7 @@ def test_float32_validation_and_timing(torch_cuda):
 # ---- dynamic walk (round 3): tiles by tickets behind two static rounds ---------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["grad", "div", "face_mass", "face_mass_b3", "batched_div_b2", "batched_div_b3"])
+@pytest.mark.parametrize("name", ["grad", "div", "face_mass", "face_mass_b3", "batched_div_b2", "batched_div_b3", "batched_grad_b2", "batched_grad_b3"])
 def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
     """Launches of five or more rounds hand their tiles to the waves by tickets (feinsum_amd/csrc/fe_common.h: dynamic walk):
     which wave computes a tile depends on timing, the result does not -- bitwise the static walk's at sizes around the
@@ -789,7 +789,8 @@ def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
     from feinsum_amd import _hip
 
     expr = {"grad": dg.grad, "div": dg.div, "face_mass": lambda: dg.face_mass(4), "face_mass_b3": lambda: dg.face_mass(3),
-            "batched_div_b2": lambda: dg.batched_div(2), "batched_div_b3": lambda: dg.batched_div(3)}[name]()
+            "batched_div_b2": lambda: dg.batched_div(2), "batched_div_b3": lambda: dg.batched_div(3),
+            "batched_grad_b2": lambda: dg.batched_grad(2), "batched_grad_b3": lambda: dg.batched_grad(3)}[name]()
     sizes = [163_840, 163_856, 200_003, 700_001, 163_840, 1_000_000, 180_000]
     before = _hip.set_tail_rounds(1 << 20)
     try:

@@ -20,7 +20,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "grad"
 E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 rounds = [int(r) for r in (sys.argv[3] if len(sys.argv) > 3 else "-1 1 2 3 6 12").split()]
 expr = {"grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4), "grad5": lambda: dg.grad(56), "div5": lambda: dg.div(56),
-        "facemass5": lambda: dg.face_mass(4, Np=56, Nfp=21), "bdiv3": lambda: dg.batched_div(3)}[what]()
+        "facemass5": lambda: dg.face_mass(4, Np=56, Nfp=21), "bdiv3": lambda: dg.batched_div(3), "bgrad3": lambda: dg.batched_grad(3)}[what]()
 nbytes = measure._get_footprint_gbytes(expr, E) * 1e9
 flops = f.count_ops(expr, long_dim_length=E)
 host = measure.generate_host_input_arrays(expr, E, np_seed=0)
