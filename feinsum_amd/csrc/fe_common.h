@@ -123,11 +123,12 @@ constexpr int kTailWords = kTailPools * kTailStride;
 // the register allocator copies the not yet written register in front of our counted wait; the compiler's own atomic is
 // followed by vmcnt(0) at once (the merge of the one-lane branch), which drains stores and prefetches every tile; an
 // accumulation register as the landing place makes the allocator spread the kernel's values over AGPRs.  So the result lands
-// in a VGPR the compiler cannot allocate: kernels with a dynamic tail are compiled with FE_TAIL_KERNEL_ATTR
-// (amdgpu_num_vgpr(248): the compiler has v0..v247), and the statements below name v255 (tickets) and v254 (the report) in
-// their text and clobber lists, which also makes the kernel descriptor allocate all 256 registers.
+// in a VGPR the compiler does not use: kernels with a dynamic walk are compiled with FE_TAIL_KERNEL_ATTR (amdgpu_num_vgpr(248):
+// the compiler is asked to stay within v0..v247, which these kernels -- 226 to 240 registers -- do anyway), and the statements
+// below name v255 (tickets) and v254 (the report) in their text and clobber lists, which also makes the kernel descriptor
+// allocate all 256 registers.  The attribute is a request, not a proof: tests/test_ticket_registers.py disassembles the BUILT
+// library and fails if any instruction outside these statements touches v254 / v255 in a kernel that takes tickets.
 #define FE_TAIL_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(248)))
-#define FE_TAIL_KERNEL_ATTR_TIGHT __attribute__((amdgpu_num_vgpr(254)))   // kernels that need all but the two ticket registers
 template <int R>
 __device__ __forceinline__ void tail_request(unsigned* counter) {
     static_assert(R == 0 || R == 1, "0: ticket (v255), 1: report (v254)");
