@@ -174,13 +174,43 @@ def compose_line(*, workload, n_gpus, steps, warmup, setup_launches=SETUP_LAUNCH
 # evidence that is not measured live: PMC counters of a committed profile
 # --------------------------------------------------------------------------
 
+def strip_c_comments(text: str) -> str:
+    """*text* (C / C++ / HIP source) without comments and with every run of white space collapsed: what the
+    compiler sees.  String and character literals are kept as they are."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == "/" and i + 1 < n and text[i + 1] == "/":
+            j = text.find("\n", i)
+            while j > 0 and text[j - 1] == "\\":          # a line comment continued by a backslash
+                j = text.find("\n", j + 1)
+            i = n if j < 0 else j
+        elif c == "/" and i + 1 < n and text[i + 1] == "*":
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        elif c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha() -> str:
-    """Hash of the kernel sources the library is built from (there is no .git on the GPU box, so
-    this -- not a commit hash -- ties a committed profile to the binary that is running)."""
+    """Hash of the kernel sources the library is built from, AS THE COMPILER SEES THEM (comments and white space
+    removed: an edit to a comment leaves the binary -- and so a committed profile of it -- valid).  There is no .git
+    on the GPU box, so this -- not a commit hash -- ties a committed profile to the binary that is running."""
     h = hashlib.sha256()
     for p in sorted((ROOT / "feinsum_amd" / "csrc").glob("*")) + [ROOT / "include" / "feinsum_hip.h"]:
+        if p.suffix not in (".h", ".hip", ".cpp", ".hpp"):
+            continue
         h.update(p.name.encode())
-        h.update(p.read_bytes())
+        h.update(strip_c_comments(p.read_text(errors="replace")).encode())
     return h.hexdigest()[:16]
 
 
@@ -478,17 +508,15 @@ def main() -> None:
     ap.add_argument("--prepare", action="store_true",
                     help="prepare the operator matrices once at bind time (fe_prepare_operator) instead of rebuilding the "
                          "MFMA fragments in every launch; measured: no gain, see DESIGN.md")
-    ap.add_argument("--placement", default="split", choices=["split", "separate", "tuned"],
+    ap.add_argument("--placement", default="split", choices=["split", "separate"],
                     help="split (default): one allocation per array, the OUTPUTS from the split allocator "
                          "(feinsum_amd.placement.zeros: 4 MiB pieces alternating between two classes of physical memory; no arena, no scan); "
-                         "separate: every array from torch; tuned (round 2): all arrays in one large arena, at the "
-                         "position that times fastest")
-    ap.add_argument("--arena-gib", type=float, default=66.0, help="size of the placement arena (tuned placement)")
+                         "separate: every array from torch")
     ap.add_argument("--no-fuse", action="store_true",
                     help="graddiv / pipeline: one launch per einsum instead of the single fused launch (A/B)")
-    ap.add_argument("--gather-fields", choices=("auto", "on", "off"), default="auto",
-                    help="after the timed region: all-gather every output field over the ranks and report the rate "
-                         "(SURVEY 8e's optional full-field exchange; auto = when there is more than one rank)")
+    ap.add_argument("--gather-fields", choices=("on", "off"), default="off",
+                    help="on: after rank 0 has printed the JSON line, all-gather every output field over the ranks and report "
+                         "the rate on stderr (SURVEY 8e's optional full-field exchange; never part of `value`)")
     ap.add_argument("--spawn-timeout", type=float, default=3000.0,
                     help="--gpus N started without a launcher: seconds the N rank processes may take")
     args = ap.parse_args()
@@ -497,6 +525,10 @@ def main() -> None:
     # HIP call here) and exits with their verdict; under torch.distributed.run the ranks arrive with their environment set
     if needs_own_ranks(args.gpus, os.environ):
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], timeout_s=args.spawn_timeout))
+    # several ranks start their allocator searches at the same instant, each on its own device but through one driver: bound
+    # what a search for a second class of memory may take (default 4 s; the arrays are then of one class and say so)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("FEINSUM_SPLIT_SEARCH_MS", "1500")
 
     # a kernel that compiled to fewer resident blocks per CU than its launch geometry assumes is an error here, not a
     # warning (feinsum_hip.hip: configure_kernel): a number taken at half the residency is not the product's
@@ -558,46 +590,7 @@ def main() -> None:
         return lambda n: op_.time_batch(n, s_)                    # same, through torch's event objects
 
     placement_report = {"mode": "separate", "what": "one torch allocation per array"}
-    if args.placement == "tuned":
-        from feinsum_amd import placement
-
-        # every array of the workload, in layout order: the inputs of all stages (sorted names; J and D of the grad /
-        # div pair once), then the outputs of all stages
-        arrays, outputs, seen = [], [], set()        # outputs: per stage
-        for k, expr in enumerate(exprs):
-            for name in sorted(expr.all_args):
-                key = name if name in ("J", "R") else f"{k}:{name}"
-                if key not in seen:
-                    seen.add(key)
-                    shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[name])
-                    arrays.append((key, shape, torch.float64))
-            out_shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
-            outputs.append([(f"{k}>{name}", out_shape, torch.float64) for name in expr.output_names])
-        # everything read first, everything written behind it, ordered so that one boundary between two classes of
-        # physical memory splits the write streams of every stage
-        arrays += placement.split_order(outputs)
-
-        def fill(key, view):
-            if ">" in key:
-                view.zero_()
-            else:
-                g = torch.Generator(device=device).manual_seed(1000 * info.rank + sum(map(ord, key)))
-                view.uniform_(0.0, 1.0, generator=g)
-
-        def stages_of(views):
-            stages, out_dicts = [], []
-            for k, expr in enumerate(exprs):
-                stages.append((expr, {name: views[name if name in ("J", "R") else f"{k}:{name}"]
-                                      for name in expr.all_args}))
-                out_dicts.append({name: views[f"{k}>{name}"] for name in expr.output_names})
-            return stages, out_dicts
-
-        arena, views, placement_report = placement.tune_base_retry(
-            arrays, device, lambda v: step_batch_of(bind(*stages_of(v))), fill=fill, attempts=3,
-            **({"stride_mib": 64, "fine_step_mib": 16, "coarse_launches": 6} if variant == "mfma_split" else {}),
-            arena_gib=args.arena_gib / max(1, info.world_size if os.environ.get("FEINSUM_DIST_BACKEND") == "gloo" else 1))
-        stages, out_dicts = stages_of(views)
-    elif args.placement == "split":
+    if args.placement == "split":
         from feinsum_amd import placement
 
         t_alloc = time.perf_counter()
@@ -698,30 +691,9 @@ def main() -> None:
                    "dynamic_rounds": "all" if rounds_setting >= (1 << 20) else rounds_setting,
                    "kernel_ms_static_walk": None if static_walk_ms is None else round(static_walk_ms, 5)}
 
+    want_gather = parallel.in_group() and args.gather_fields == "on"
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
-
-    # the optional full-field exchange (off the clock; never part of `value`): the one place xGMI carries data
-    field_gather = None
-    if parallel.in_group() and (args.gather_fields == "on" or (args.gather_fields == "auto" and info.world_size > 1)):
-        lengths = {E} if not args.elems_total else \
-            {b - a for a, b in (parallel.shard_bounds(args.elems_total, info.world_size, r) for r in range(info.world_size))}
-        if len(lengths) != 1:               # (every rank computes the same set: no rank enters the collective alone)
-            field_gather = {"skipped": "shards of unequal length"}
-        else:
-            try:
-                axes = [[i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
-                        for expr in exprs for _ in expr.output_names]
-                g = parallel.allgather_fields_timed(list(zip(outs_all, axes)), sync)
-                sums = g.pop("sums")
-                g["matches_reduction"] = bool(all(abs(a - float(b)) <= 1e-9 * max(1.0, abs(float(b)))
-                                                  for a, b in zip(sums, total[:, 0].tolist())))
-                g["ms"], g["gbps_per_gpu"] = round(g["ms"], 3), round(g["gbps_per_gpu"], 1)
-                g["backend"] = info.backend           # nccl = RCCL over xGMI; gloo (rehearsals) goes through host memory
-                g["xgmi_peak_gbps_per_gpu"] = 7 * 153.0
-                field_gather = g
-            except Exception as exc:      # an optional exchange must not cost the line
-                field_gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # flops of the whole job = sum over ranks (ranks may hold different element counts)
     flops_all = flops_step
@@ -743,7 +715,10 @@ def main() -> None:
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
                  "walk": walk_report,
-                 "dist_backend": info.backend if parallel.in_group() else None, "field_allgather": field_gather,
+                 "dist_backend": info.backend if parallel.in_group() else None,
+                 # the optional full-field exchange runs BEHIND this line (rank 0 reports it on stderr): whatever happens
+                 # inside a 6.7 GB-per-GPU collective cannot cost the scaling record
+                 "field_allgather": "off" if not want_gather else "runs after this line; reported on stderr as `field_allgather {...}`",
                  # how many ranks the process group really holds (1 without a group), and who started them
                  "ranks_seen": ranks_seen,
                  "launcher": os.environ.get("FEINSUM_BENCH_LAUNCHER") or
@@ -781,6 +756,33 @@ def main() -> None:
         if info.world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, full=args.cpu_baseline == "full")
         print(json.dumps(line), flush=True)
+
+    # the optional full-field exchange (off the clock; never part of `value`): the one place xGMI carries data.  It runs
+    # AFTER rank 0 has printed the line.  No rank enters a collective alone: the shard lengths are computed alike on every
+    # rank, every rank stages its receive buffers first (the likely failure: 6.7 GB per GPU for grad at 8 ranks) and the
+    # ranks agree on the outcome with one all-reduce of a flag (parallel.allgather_fields_timed).
+    if want_gather:
+        lengths = {E} if not args.elems_total else \
+            {b - a for a, b in (parallel.shard_bounds(args.elems_total, info.world_size, r) for r in range(info.world_size))}
+        if len(lengths) != 1:
+            field_gather = {"skipped": "shards of unequal length"}
+        else:
+            try:
+                axes = [[i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
+                        for expr in exprs for _ in expr.output_names]
+                g = parallel.allgather_fields_timed(list(zip(outs_all, axes)), sync)
+                if "sums" in g:
+                    sums = g.pop("sums")
+                    g["matches_reduction"] = bool(all(abs(a - float(b)) <= 1e-9 * max(1.0, abs(float(b)))
+                                                      for a, b in zip(sums, total[:, 0].tolist())))
+                    g["ms"], g["gbps_per_gpu"] = round(g["ms"], 3), round(g["gbps_per_gpu"], 1)
+                    g["backend"] = info.backend           # nccl = RCCL over xGMI; gloo (rehearsals) goes through host memory
+                    g["xgmi_peak_gbps_per_gpu"] = 7 * 153.0
+                field_gather = g
+            except Exception as exc:      # noqa: BLE001  (reported; the line is out already)
+                field_gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if info.rank == 0:
+            print("field_allgather " + json.dumps(field_gather), file=sys.stderr, flush=True)
 
     if parallel.in_group():
         import torch.distributed as dist

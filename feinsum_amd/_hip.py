@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
     "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
+    "fe_set_cu_limit", "fe_stream_retired", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -162,6 +163,17 @@ def load_library() -> C.CDLL:
     lib.fe_split_trim.argtypes = []
     lib.fe_set_tail_rounds.restype = C.c_int
     lib.fe_set_tail_rounds.argtypes = [C.c_int32]
+    lib.fe_set_temporal_loads_mib.restype = C.c_int
+    lib.fe_set_temporal_loads_mib.argtypes = [C.c_int32]
+    lib.fe_set_cu_limit.restype = C.c_int
+    lib.fe_set_cu_limit.argtypes = [C.c_int32]
+    lib.fe_stream_retired.restype = C.c_int
+    lib.fe_stream_retired.argtypes = [C.c_void_p]
+    lib.fe_tail_plant.restype = C.c_int
+    lib.fe_tail_plant.argtypes = [C.c_void_p, C.c_uint32]
+    lib.fe_tail_check.restype = C.c_int
+    lib.fe_tail_check.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]
     lib.fe_launch_f32.restype = C.c_int
     lib.fe_launch_f32.argtypes = [C.c_int32, C.POINTER(ArgPack), C.c_void_p]
     lib.fe_prepare_operator.restype = C.c_int
@@ -395,3 +407,37 @@ def set_tail_rounds(rounds: int) -> int:
     """Number of dynamic rounds at the end of the persistent walks (fe_set_tail_rounds; negative: static walk); returns the
     previous value.  A tuning knob -- results do not depend on it."""
     return int(load_library().fe_set_tail_rounds(int(rounds)))
+
+
+def set_cu_limit(cus: int) -> int:
+    """Size the persistent grids as if the device had *cus* compute units (fe_set_cu_limit; 0 = the device's own count);
+    returns the previous limit.  Results do not depend on it."""
+    return int(load_library().fe_set_cu_limit(int(cus)))
+
+
+def stream_retired(stream: int) -> bool:
+    """Tell the library that *stream* was destroyed, so that its ticket-counter group can serve another stream."""
+    rc = int(load_library().fe_stream_retired(stream))
+    if rc < 0:
+        check(rc)
+    return rc == 1
+
+
+def tail_check(repair: bool = False) -> dict:
+    """Wait for the device and verify that every ticket counter is zero (fe_tail_check): ``dirty_words`` must be 0."""
+    dirty, groups, streams, captured = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(load_library().fe_tail_check(int(bool(repair)), C.byref(dirty), C.byref(groups), C.byref(streams),
+                                       C.byref(captured)))
+    return {"dirty_words": int(dirty.value), "groups": int(groups.value), "streams": int(streams.value),
+            "captured": int(captured.value)}
+
+
+def tail_plant(stream: int, value: int) -> None:
+    """Test hook (fe_tail_plant): leave a stale ticket in the counter group of *stream*."""
+    check(load_library().fe_tail_plant(stream, int(value)))
+
+
+def set_temporal_loads_mib(mib: int) -> int:
+    """Launches whose inputs are at most *mib* MiB fetch their streamed operand with plain (cacheable) loads instead of
+    non-temporal ones (fe_set_temporal_loads_mib; 0 = never); returns the previous setting.  A tuning knob."""
+    return int(load_library().fe_set_temporal_loads_mib(int(mib)))

@@ -87,6 +87,16 @@ __device__ __forceinline__ void glds4(const void* g, unsigned lds_base) {
         : "memory");
 }
 
+// The streamed operand of a launch (u / v: every byte read once per launch) is fetched non-temporally -- unless the launch's
+// inputs fit the 256 MiB Infinity Cache: then a caller who evaluates again and again on the same arrays (a time stepper; the
+// reference's timing protocol, src/feinsum/measure.py:248-275) finds them there the next time, IF the loads were allowed to
+// allocate.  Measured (profiles/r04/temporal_loads_ab.txt, grad, back-to-back launches): E = 1e5 24.8 -> 23.1 us, 2e5 43.1 ->
+// 41.1, 5e5 96.3 -> 92.2, 7e5 132.0 -> 125.9 (inputs 235 MiB); 7.5e5 (252 MiB) level, 8e5 149.2 -> 167.3 and 1e6 184.8 ->
+// 197.3 (the inputs no longer fit: the cache thrashes).  Stores stay non-temporal at every size (temporal: +9 % at 1e5,
+// +21 % at 5e5).  The launcher sets kOpLoadsTemporal in a body's flag word when the launch reads at most kTemporalInputBytes.
+constexpr int kOpLoadsTemporal = 16;
+constexpr long long kTemporalInputBytes = 248ll << 20;
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -166,6 +176,14 @@ __device__ __forceinline__ int64_t tail_ticket_tile(unsigned t, int64_t t_static
     const unsigned off = t * (unsigned)kTailPools + (((unsigned)pool + t) & (unsigned)(kTailPools - 1));   // (the pool's residue rotates: see above)
     const bool ok = t < (1u << 26) && off < room;
     return ok ? t_static + (int64_t)off : (int64_t)-1;
+}
+
+// the ticket counter of a pool (its report counter lies kTailStride / 2 words behind); null for a launch without counters
+__device__ __forceinline__ unsigned* tail_pool_counters(unsigned* tail, int pool) {
+    return tail ? tail + pool * kTailStride : nullptr;
+}
+__device__ __forceinline__ unsigned* tail_pool_reports(unsigned* counter) {
+    return counter ? counter + kTailStride / 2 : nullptr;
 }
 
 // Orders this wave's LDS accesses for the compiler.  The hardware executes one

@@ -130,6 +130,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
+    const bool tload = (op_flags & kOpLoadsTemporal) != 0;   // the u planes by plain loads (fe_common.h)
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,13 +218,24 @@ __device__ __forceinline__ void div3d_mfma_body(
     auto issue_loads = [&](int64_t tile, int fk, bool with_j) {
         const int64_t e0 = phys(tile) * G::TEL;
         const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);
+        if (tload) {   // (fe_common.h, kOpLoadsTemporal: one scalar branch for the whole unit)
 #pragma unroll
-        for (int x = 0; x < G::NPLANES; ++x) {
-            const char* up = ub + (int64_t)x * E * (NP * 8);
+            for (int x = 0; x < G::NPLANES; ++x) {
+                const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
-            for (int c = 0; c < G::P_INSTR; ++c)
-                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
-                    glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+                for (int c = 0; c < G::P_INSTR; ++c)
+                    if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                        glds16(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < G::NPLANES; ++x) {
+                const char* up = ub + (int64_t)x * E * (NP * 8);
+#pragma unroll
+                for (int c = 0; c < G::P_INSTR; ++c)
+                    if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                        glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+            }
         }
         if (!with_j) return;
         const char* jb = reinterpret_cast<const char*>(J) + e0 * 8;
@@ -434,8 +446,8 @@ __device__ __forceinline__ void div3d_mfma_body(
         // its last plane, where the next tile's loads are issued
         const bool dyn8 = kDyn && tail != nullptr && t_static < nTiles && nb == 1;   // grid-uniform
         const int pool8 = (bid >> 3) & (kTailPools - 1);
-        unsigned* const counter8 = tail + pool8 * kTailStride;
-        unsigned* const done8 = counter8 + kTailStride / 2;
+        unsigned* const counter8 = tail_pool_counters(tail, pool8);
+        unsigned* const done8 = tail_pool_reports(counter8);
         bool reported8 = false;
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
@@ -632,8 +644,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     // the ticket for the next tile is asked for with the tile's first field and read with its last, b - 1 units later.
     const bool dyn = kDyn && tail != nullptr && t_static < nTiles && !split_walk;   // grid-uniform
     const int pool = (bid >> 3) & (kTailPools - 1);
-    unsigned* const counter = tail + pool * kTailStride;
-    unsigned* const done = counter + kTailStride / 2;
+    unsigned* const counter = tail_pool_counters(tail, pool);
+    unsigned* const done = tail_pool_reports(counter);
     bool pending = false, reported = false;
     auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
     while (tile < tEnd) {

@@ -72,14 +72,26 @@ __device__ __forceinline__ void fm_issue_unit_loads(const double* __restrict__ J
     using G = FmGeom<NP, NFP, M, NF, ALDS, W8>;
     const int64_t e0 = tile * G::TEL;
     const char* vb = reinterpret_cast<const char*>(vk) + e0 * (NFP * 8) + lane * 16;
+    if (jfe & kOpLoadsTemporal) {   // (fe_common.h: one scalar branch for the whole unit)
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const char* vf = vb + (int64_t)f * E * (NFP * 8);
+        for (int f = 0; f < NF; ++f) {
+            const char* vf = vb + (int64_t)f * E * (NFP * 8);
 #pragma unroll
-        for (int c = 0; c < G::SLAB_INSTR; ++c)
-            if ((c + 1) * 64 <= G::SLAB_CHUNKS || c * 64 + lane < G::SLAB_CHUNKS)
-                glds16_nt(vf + c * 1024, lds_v + f * (G::SLAB_D * 8) + c * 1024);
+            for (int c = 0; c < G::SLAB_INSTR; ++c)
+                if ((c + 1) * 64 <= G::SLAB_CHUNKS || c * 64 + lane < G::SLAB_CHUNKS)
+                    glds16(vf + c * 1024, lds_v + f * (G::SLAB_D * 8) + c * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const char* vf = vb + (int64_t)f * E * (NFP * 8);
+#pragma unroll
+            for (int c = 0; c < G::SLAB_INSTR; ++c)
+                if ((c + 1) * 64 <= G::SLAB_CHUNKS || c * 64 + lane < G::SLAB_CHUNKS)
+                    glds16_nt(vf + c * 1024, lds_v + f * (G::SLAB_D * 8) + c * 1024);
+        }
     }
+    jfe &= 1;
     if (kWithJ) {
         const char* jb = reinterpret_cast<const char*>(J);
 #pragma unroll
@@ -104,8 +116,9 @@ template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, boo
           bool kDyn = false>
 __device__ __forceinline__ void facemass_mfma_body(
     const double* __restrict__ J, const double* __restrict__ R, const void* __restrict__ prep, const FieldPtrs& P,
-    int64_t E, int64_t nTiles, int jfe, int rlayout, const unsigned bid, const unsigned nblk,
+    int64_t E, int64_t nTiles, int jfe_flags, int rlayout, const unsigned bid, const unsigned nblk,
     unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
+    const int jfe = jfe_flags & 1;   // J stored [nf][E]; bit kOpLoadsTemporal: the field slabs by plain loads (fe_common.h)
     static_assert(!kPrep || !ALDS, "prepared operators: fragments in registers");
     static_assert(!kDyn || (NB >= 3 && !ALDS && !W8 && !kPrep) || (NB >= 2 && ALDS && W8),
                   "dynamic walk: three or more fields with the fragments in registers, or the eight-wave blocks (p = 5)");
@@ -207,14 +220,14 @@ __device__ __forceinline__ void facemass_mfma_body(
     if constexpr (W8) {
         // ---- eight waves per block: wait the unit -> B to registers -> MFMAs -> o through the slab
         //      buffer -> stores -> request the next unit
-        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
+        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe_flags);
         double jv8[G::KS];
         // dynamic walk (fe_common.h): the ticket for the next tile is asked for with unit 0 (behind the vmcnt(0) at its top)
         // and read behind the last unit's stores, where the next tile's first unit is requested
         const bool dyn8 = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
         const int pool8 = (bid >> 3) & (kTailPools - 1);
-        unsigned* const counter8 = tail + pool8 * kTailStride;
-        unsigned* const done8 = counter8 + kTailStride / 2;
+        unsigned* const counter8 = tail_pool_counters(tail, pool8);
+        unsigned* const done8 = tail_pool_reports(counter8);
         bool reported8 = false;
         int64_t tile = first;
         while (tile < tEnd) {
@@ -280,7 +293,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                 wave_lds_fence();
                 // ---- the next unit: the next field of this tile, or field 0 (and J) of the next tile
                 if (k + 1 < NB) {
-                    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[(k + 1) % NB], E, tile, lane, lds_v0, lds_j, jfe);
+                    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[(k + 1) % NB], E, tile, lane, lds_v0, lds_j, jfe_flags);
                 } else {
                     if constexpr (kDyn) {
                         if (asked8) {   // younger than the request by now: this unit's stores (every unit starts with vmcnt(0))
@@ -292,7 +305,7 @@ __device__ __forceinline__ void facemass_mfma_body(
                             }
                         }
                     }
-                    if (nt < tEnd) fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, nt, lane, lds_v0, lds_j, jfe);
+                    if (nt < tEnd) fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, nt, lane, lds_v0, lds_j, jfe_flags);
                 }
             }
             tile = nt;
@@ -311,8 +324,8 @@ __device__ __forceinline__ void facemass_mfma_body(
     }
 
     // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe);
-    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe);
+    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe_flags);
+    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe_flags);
     if constexpr (kPrep) prepared_fragments_landed();
 
     int slot = 0;
@@ -322,8 +335,8 @@ __device__ __forceinline__ void facemass_mfma_body(
     int iteration = 0;
     const bool dyn = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
     const int pool = (bid >> 3) & (kTailPools - 1);
-    unsigned* const counter = tail + pool * kTailStride;
-    unsigned* const done = counter + kTailStride / 2;
+    unsigned* const counter = tail_pool_counters(tail, pool);
+    unsigned* const done = tail_pool_reports(counter);
     bool reported = false;
     int64_t tile = first;
     while (tile < tEnd) {
@@ -391,10 +404,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 if (tile2 < tEnd) {
                     if (k2 == 0)
                         fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[k2], E, tile2, lane,
-                                                              lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
+                                                              lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe_flags);
                     else
                         fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[k2], E, tile2, lane,
-                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe);
+                                                               lds_v0 + slot * (G::UNIT_D * 8), lds_j, jfe_flags);
                 }
             }
 

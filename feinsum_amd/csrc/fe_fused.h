@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_ker
     // (Two straight-line sequences, not a loop over the bodies: in a loop the register allocator keeps state of one
     // body alive across the other and spills -- 408 bytes of scratch per lane and 4.7 % more HBM traffic, measured.)
     const bool swap = ((opT & 256) && blockIdx.x >= gridDim.x / 2) || ((opT & 512) && (blockIdx.x & 1));
-    const int op = opT & 1;
+    const int op = opT & (1 | kOpLoadsTemporal);
 #ifdef FE_EXPERIMENTS
     if ((opT & 1024) && gridDim.x >= 2 && (gridDim.x & 1) == 0) {
         // ROLE SPLIT (bit 10; experiment build only -- measured in round 3 and 0.5 % slower): the older half of the grid runs div over ALL tiles,
@@ -111,6 +111,7 @@ struct WaveOpArgs {
     int64_t E, nTilesG, nTilesD, nTilesF;
     int jfe, rlayout;
     int order;           // 0: every block div, grad, lift; 3: the younger half of the grid grad, div, lift
+    int load_flags;      // 0 or kOpLoadsTemporal (fe_common.h): the launch's inputs fit the Infinity Cache
 };
 
 template <int NP, int NFP, int MG, int MD, int MF, int NB, bool kPrep = false, bool kDyn = false>
@@ -123,20 +124,20 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void waveop3d_mfma_kern
     // order 3: the younger half of the grid runs grad before div (see graddiv3d_mfma_kernel); the lift comes last everywhere
     const bool swap = a.order == 3 && blockIdx.x >= gridDim.x / 2;
     if (!swap) {
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, a.load_flags, 0, blockIdx.x,
                                                                     gridDim.x, nullptr, tail_d, ft.static_d);
         body_boundary();
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
-                                                       a.nTilesG, 0, blockIdx.x, gridDim.x, tail_g, ft.static_g);
+                                                       a.nTilesG, a.load_flags, blockIdx.x, gridDim.x, tail_g, ft.static_g);
     } else {
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
-                                                       a.nTilesG, 0, blockIdx.x, gridDim.x, tail_g, ft.static_g);
+                                                       a.nTilesG, a.load_flags, blockIdx.x, gridDim.x, tail_g, ft.static_g);
         body_boundary();
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, 0, 0, blockIdx.x,
+        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, a.load_flags, 0, blockIdx.x,
                                                                     gridDim.x, nullptr, tail_d, ft.static_d);
     }
     body_boundary();
-    facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep, kDynF>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe,
+    facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep, kDynF>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe | a.load_flags,
                                                                            a.rlayout, blockIdx.x, gridDim.x, tail_f, ft.static_f);
 }
 

@@ -143,17 +143,21 @@ __device__ __forceinline__ void wait_vmcnt_planes(int nx) {
     else wait_vmcnt<BASE + PER>();
 }
 
+// `temporal` (wave-uniform; fe_common.h, kOpLoadsTemporal): plain loads, one scalar branch for the whole tile
 template <int NP, int M, bool kNT = true>
 __device__ __forceinline__ void grad_issue_u(const double* __restrict__ u, int64_t tile, int lane,
-                                             unsigned lds_u) {
+                                             unsigned lds_u, bool temporal = false) {
     using G = GradGeom<NP, M>;
     const char* ub = reinterpret_cast<const char*>(u) + tile * (G::TEL * NP * 8) + lane * 16;
+    if (!kNT || temporal) {
 #pragma unroll
-    for (int c = 0; c < G::U_INSTR; ++c)
-        if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) {
-            if (kNT) glds16_nt(ub + c * 1024, lds_u + c * 1024);
-            else glds16(ub + c * 1024, lds_u + c * 1024);
-        }
+        for (int c = 0; c < G::U_INSTR; ++c)
+            if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) glds16(ub + c * 1024, lds_u + c * 1024);
+    } else {
+#pragma unroll
+        for (int c = 0; c < G::U_INSTR; ++c)
+            if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) glds16_nt(ub + c * 1024, lds_u + c * 1024);
+    }
 }
 
 // kPlain: the planes are those of one 'xre,rij,ej->xei' (j[x] = j[0] + 3 x E, out[k][x] =
@@ -184,6 +188,7 @@ __device__ __forceinline__ void grad_issue_j(const GradFields& P, int64_t E, int
 // {kernel entry, main-loop start, main-loop end, XCC_ID | HW_ID << 8}.
 __device__ unsigned long long fe_dbg_clock[2];
 __device__ unsigned long long fe_dbg_stamps[4096][4];
+__device__ unsigned long long fe_dbg_phase[4096][4];   // prologue: operator landed, barrier passed, fragments built, second barrier passed
 #endif
 
 // kDbg: experiment flags, 0 in the product build (tools/fe_check.cpp "ab" mode uses the others
@@ -204,9 +209,11 @@ __device__ unsigned long long fe_dbg_stamps[4096][4];
 template <int NP, int M, int kDbg = 0, bool kPlain = true, bool kPrep = false, bool kDyn = false>
 __device__ __forceinline__ void grad3d_mfma_body(
     const GradFields& P, const double* __restrict__ D, const void* __restrict__ prep, int nb, int nx_, int64_t E,
-    int64_t nTiles, int opT, const unsigned bid, const unsigned nblk, unsigned* __restrict__ tail = nullptr,
+    int64_t nTiles, int op_flags, const unsigned bid, const unsigned nblk, unsigned* __restrict__ tail = nullptr,
     int64_t t_static = 0) {
     static_assert(!kDyn || (kPlain && !kPrep), "dynamic walk: plain launches of one field");
+    const int opT = op_flags & 1;                                  // operator stored transposed
+    const bool tload = (op_flags & kOpLoadsTemporal) != 0;         // the u tiles by plain loads (fe_common.h)
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -233,15 +240,15 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // the loads of this wave's first two units (behind the operator copy / the fragment loads)
     auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
         if (!(tile < tEnd) || (kDbg & 8)) return 0;
-        grad_issue_u<NP, M, kNT>(P.u[0], phys(tile), lane, lds_addr_uniform(L->u[0]));
+        grad_issue_u<NP, M, kNT>(P.u[0], phys(tile), lane, lds_addr_uniform(L->u[0]), tload);
         grad_issue_j<NP, M, kPlain>(P, E, phys(tile), lane, lds_addr_uniform(L->j[0]));
         if (nb > 1) {
-            grad_issue_u<NP, M, kNT>(P.u[1], phys(tile), lane, lds_addr_uniform(L->u[1]));
+            grad_issue_u<NP, M, kNT>(P.u[1], phys(tile), lane, lds_addr_uniform(L->u[1]), tload);
             pre = true;
             return 1;
         }
         if (tile + stride < (dyn ? t_static : tEnd)) {
-            grad_issue_u<NP, M, kNT>(P.u[0], phys(tile + stride), lane, lds_addr_uniform(L->u[1]));
+            grad_issue_u<NP, M, kNT>(P.u[0], phys(tile + stride), lane, lds_addr_uniform(L->u[1]), tload);
             grad_issue_j<NP, M, kPlain>(P, E, phys(tile + stride), lane, lds_addr_uniform(L->j[1]));
             pre = true;
             return 2;
@@ -261,10 +268,19 @@ __device__ __forceinline__ void grad3d_mfma_body(
             case 3: wait_vmcnt<G::LOADS>(); break;
             default: wait_vmcnt<0>(); break;
         }
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][0] = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // ---- A fragments from the staged operator (addresses = row part + column part: the 63
         //      fragments of p = 4 cost one add and one LDS read each)
+#ifdef FE_BUILD_PRIO
+        if (FE_BUILD_PRIO == 2 || bid >= (nblk + 1) / 2) __builtin_amdgcn_s_setprio(3);
+#endif
         const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
         const int gp = n & 3, q = n >> 2;
         const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
@@ -288,7 +304,19 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 afrag[t][ks] = (rowok && jok[ks]) ? v : 0.0;
             }
         }
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fe_dbg_phase[bid * G::WAVES + wave][2] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+#ifdef FE_BUILD_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();   // the staging area becomes the waves' output buffers
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][3] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 
     remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
@@ -397,8 +425,8 @@ __device__ __forceinline__ void grad3d_mfma_body(
             //      every wave has a static first tile (t_static >= number of waves).
             constexpr int NL = G::LOADS, NS = G::STORES;
             const int pool = (bid >> 3) & (kTailPools - 1);
-            unsigned* const counter = tail + pool * kTailStride;
-            unsigned* const done = counter + kTailStride / 2;   // the pool's report counter, half a stride behind its tickets
+            unsigned* const counter = tail_pool_counters(tail, pool);
+            unsigned* const done = tail_pool_reports(counter);   // the pool's report counter, half a stride behind its tickets
             // waves of this pool: blocks b with (b / 8) % kTailPools == pool
             const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 +
                                          (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
@@ -433,7 +461,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                         extra = true;
                     }
                     if (!pre) {
-                        grad_issue_u<NP, M, kNT>(P.u[0], nxt, lane, lds_addr_uniform(L->u[buf ^ 1]));
+                        grad_issue_u<NP, M, kNT>(P.u[0], nxt, lane, lds_addr_uniform(L->u[buf ^ 1]), tload);
                         grad_issue_j<NP, M, kPlain>(P, E, nxt, lane, lds_addr_uniform(L->j[buf ^ 1]));
                     }
                 }
@@ -478,8 +506,8 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // for it (everything but the previous unit's stores) is the wait for this unit's loads as well
     const bool dynb = kDyn && dyn && nb >= 2;   // grid-uniform
     const int poolb = (bid >> 3) & (kTailPools - 1);
-    unsigned* const counterb = tail + poolb * kTailStride;
-    unsigned* const doneb = counterb + kTailStride / 2;
+    unsigned* const counterb = tail_pool_counters(tail, poolb);
+    unsigned* const doneb = tail_pool_reports(counterb);
     bool pendingb = false, reportedb = false;
     while (tile < tEnd) {
         balance_priority(younger_half, iteration++);
@@ -516,7 +544,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
         if (kDbg & 8) {
             wait_vmcnt<0>();
         } else if (nt < tEnd) {
-            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]));
+            if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]), tload);
             if (next_new_tile) {
                 if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
                 if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();

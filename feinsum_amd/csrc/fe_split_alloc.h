@@ -139,6 +139,7 @@ class SplitPool {
         if (const char* thr = getenv("FEINSUM_SPLIT_OTHER_ABOVE_GBPS")) other_above_gbps_ = atof(thr);
         if (const char* gib = getenv("FEINSUM_SPLIT_SEARCH_GIB")) search_budget_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
         if (const char* ms = getenv("FEINSUM_SPLIT_SEARCH_MS")) search_ms_budget_ = atof(ms);
+        if (const char* gib = getenv("FEINSUM_SPLIT_VA_GIB")) va_cap_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
         // the anchor of class 0: ONE handle of 256 MiB (a single block of the driver's allocator, hence of one class --
         // a group of 32 small handles may straddle two runs, and an impure anchor makes every later reading ambiguous:
         // profiles/r03/split_alloc_check_v10_group_anchors_impure.txt); it stays mapped for the life of the process
@@ -218,6 +219,8 @@ class SplitPool {
         return FE_OK;
     }
 
+    bool owns(const void* ptr) const { return live_.count(static_cast<char*>(const_cast<void*>(ptr))) != 0; }
+
     int free_array(void* ptr) {
         auto it = live_.find(static_cast<char*>(ptr));
         if (it == live_.end()) return fail(FE_EINVAL, "fe_split_free: %p is not an array of the split allocator", ptr);
@@ -259,11 +262,11 @@ class SplitPool {
                         "\"live_arrays\": %zu, \"pieces_created\": %zu, \"groups_probed\": %zu, \"probes\": %zu, \"spacer_bytes_peak\": %zu, "
                         "\"spacers_created\": %zu, \"spacer_ms\": %.1f, \"probe_ms\": %.1f, \"groups_discarded\": %zu, \"unsplit_arrays\": %zu, \"setup_ms\": %.3f, \"alloc_ms_total\": %.3f, "
                         "\"same_class_below_gbps\": %.0f, \"walk_gave_up\": %s, \"piece_mib\": %zu, \"group_mib\": %zu, "
-                        "\"address_space_reserved\": %zu, \"last_probes_gbps\": \"%s\"}",
+                        "\"address_space_reserved\": %zu, \"address_space_cap\": %zu, \"last_probes_gbps\": \"%s\"}",
                         ready_ ? "true" : "false", free_.size(), fr.c_str(), pooled * kSplitPiece, live_bytes_, live_.size(),
                         pieces_created_, groups_probed_, probes_, spacer_bytes_peak_, spacers_created_, spacer_ms_, probe_ms_, groups_discarded_, unsplit_arrays_, setup_ms_,
                         alloc_ms_total_, same_below_gbps_, walk_gave_up_ ? "true" : "false", kSplitPiece / kSplitMiB,
-                        kSplitGroupBytes / kSplitMiB, va_reserved_, last_probes_.c_str());
+                        kSplitGroupBytes / kSplitMiB, va_reserved_, va_cap_, last_probes_.c_str());
     }
 
     // The caller is about to allocate arrays of `bytes` bytes in all: collect half of that of each of two classes NOW, while
@@ -304,6 +307,7 @@ class SplitPool {
     double spacer_ms_ = 0, probe_ms_ = 0;
     size_t search_budget_ = 96ull << 30;   // how far a search for another class may skip ahead ($FEINSUM_SPLIT_SEARCH_GIB)
     size_t groups_discarded_ = 0;
+    size_t va_cap_ = 16ull << 40;          // reserved address space this pool may reach ($FEINSUM_SPLIT_VA_GIB)
     double search_ms_budget_ = 4000.0;     // ... and how long the skipping itself may take ($FEINSUM_SPLIT_SEARCH_MS)
     std::vector<hipMemGenericAllocationHandle_t> discarded_;   // pieces of ambiguous groups: held while a search runs
     size_t pieces_created_ = 0, groups_probed_ = 0, probes_ = 0, spacer_bytes_peak_ = 0, spacers_created_ = 0, unsplit_arrays_ = 0;
@@ -348,6 +352,13 @@ class SplitPool {
     int fresh_range(size_t bytes, char** out) {
         bytes = (bytes + kSplitGran - 1) / kSplitGran * kSplitGran;
         char* base = nullptr;
+        // ranges are never handed back (see the header), so a process that allocates and frees for ever grows its reserved
+        // address space without bound: a documented cap ($FEINSUM_SPLIT_VA_GIB, default 16 TiB of the device's 2^47-byte
+        // space -- 20 000 allocate / free cycles of the headline grad output) turns that into an error the host code answers
+        // by allocating ordinarily (placement.empty falls back to torch)
+        if (va_reserved_ + bytes > va_cap_)
+            return fail(FE_EHIP, "split allocator: address-space cap reached (%zu GiB reserved, cap %zu GiB: FEINSUM_SPLIT_VA_GIB)",
+                        va_reserved_ >> 30, va_cap_ >> 30);
         hipError_t e = hipMemAddressReserve((void**)&base, bytes, kSplitGran, nullptr, 0);
         if (e != hipSuccess) return fail(FE_EHIP, "split allocator: no address space (%zu bytes): %s", bytes, hipGetErrorString(e));
         va_reserved_ += bytes;
@@ -620,5 +631,29 @@ SplitPool* split_pool_of_current_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     return &g_split_pools[dev];
 }
+
+// The device whose pool holds the array `ptr`: the current device's pool is asked first, then the others' (an array may be
+// freed or asked about from a thread whose current device is another one); -1 if no pool knows it.
+int split_owner_device(const void* ptr) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= 64) cur = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int dev = (cur + k) % 64;
+        std::lock_guard<std::mutex> lock(g_split_pools[dev].mu);
+        if (g_split_pools[dev].owns(ptr)) return dev;
+    }
+    return -1;
+}
+// Makes `dev` the current device for the lifetime of the object (the pool's HIP calls act on the current device).
+struct SplitDeviceScope {
+    int before = -1;
+    bool switched = false;
+    explicit SplitDeviceScope(int dev) {
+        if (hipGetDevice(&before) == hipSuccess && before != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~SplitDeviceScope() {
+        if (switched) (void)hipSetDevice(before);
+    }
+};
 
 }  // namespace

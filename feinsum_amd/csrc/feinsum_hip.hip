@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "../../include/feinsum_hip.h"
 #include "fe_common.h"
@@ -47,18 +48,22 @@ int fail(int code, const char* fmt, ...) {
 
 // Persistent-style grid: enough blocks to fill every CU at the kernel's
 // residency (2 blocks of 256 threads per CU), capped by the work available.
+std::atomic<int> g_cu_limit{[] { const char* e = getenv("FEINSUM_CU_LIMIT"); return e ? atoi(e) : 0; }()};
 int device_cu_count() {
+    // fe_set_cu_limit / FEINSUM_CU_LIMIT: size the persistent grids as if the device had fewer CUs (a CPX / QPX partition
+    // of MI355X reports 32 / 64) -- a test hook for the small-grid paths, and a way to leave part of the device to others
+    const int limit = g_cu_limit.load(std::memory_order_relaxed);
     static int cus[64];
     static std::once_flag once[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return limit > 0 && limit < 256 ? limit : 256;
     std::call_once(once[dev], [dev] {
         hipDeviceProp_t p;
         cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
                        ? p.multiProcessorCount
                        : 256;
     });
-    return cus[dev];
+    return limit > 0 && limit < cus[dev] ? limit : cus[dev];
 }
 
 // Resources of every kernel configured so far in this process (fe_kernel_resources).
@@ -145,57 +150,147 @@ int check_common(const void* J, const void* D, const void* u, const void* out, i
 
 unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 256); }
 
-// ---- dynamic walk (fe_common.h): the ticket counters of a launch.  One zeroed buffer of kTailSlots slots per device, taken
-// the first time a launch wants it (not during stream capture: then, and when the allocation fails, the launch walks
-// statically); launches take the slots in turn, so that launches running at the same time on different streams have their
-// own counters; a launch leaves its slot zeroed.
-constexpr int kTailSlots = 64;
-struct TailBuffers {
+// ---- dynamic walk (fe_common.h): the ticket counters of a launch.
+// Who may share counters: nobody who can run at the same time.  A launch's counters are zero before and after it (the
+// kernels clean up behind themselves), so launches that the device SERIALISES may use the same ones; launches that can
+// overlap must not (two launches drawing from one counter take each other's tiles -- silently).  Ownership therefore
+// follows what orders launches:
+//  * an eager launch uses the counter group of ITS STREAM (a per-device map stream -> group; the per-thread default
+//    stream is a different stream in every thread and is keyed by the thread).  Launches on one stream run one after the
+//    other; two streams -- driven from one host thread or from several -- never share a group;
+//  * a launch recorded during stream capture gets a group of ITS OWN, for good: the graph node bakes the pointer in and
+//    may be replayed on any stream beside any eager launch (launches of one executable graph are ordered by HIP);
+//  * a group is four consecutive counter sets (a fused launch uses one set per body);
+//  * groups come from chunks of kTailChunkGroups, allocated and zeroed outside stream capture only (a capture that finds
+//    no spare group walks statically, and so does everything once kTailMaxGroups exist: the static walk needs no state);
+//  * fe_stream_retired() returns a destroyed stream's group; fe_tail_check() verifies the zero-between-launches invariant
+//    on an idle device (and repairs it), FEINSUM_TAIL_CHECK=1 does so before every dynamic launch (debugging aid: it
+//    synchronises the stream).
+constexpr int kTailSetsPerGroup = 4;
+constexpr int kTailChunkGroups = 16;                     // 8.9 MB per chunk
+constexpr int kTailMaxGroups = 256;                      // per device
+constexpr size_t kTailGroupWords = (size_t)kTailSetsPerGroup * fe::kTailWords;
+struct TailPool {
     std::mutex lock;
-    std::atomic<unsigned*> base[64];   // (static storage: null)
-    bool failed[64] = {};
-    std::atomic<unsigned> next[64];
+    std::unordered_map<uintptr_t, unsigned*> by_stream;   // eager launches
+    std::vector<unsigned*> spare;                          // zeroed groups nobody owns
+    std::vector<unsigned*> chunks;                         // every allocation (fe_tail_check walks them)
+    int groups = 0, captured = 0;
+    bool failed = false;
+    hipStream_t zero_stream = nullptr;
+    // a fresh chunk: zeroed through a stream of our own and waited for, so that whoever takes a group later -- on any
+    // stream -- finds zeros without being ordered behind anything
+    bool grow() {
+        if (failed || groups + kTailChunkGroups > kTailMaxGroups) return false;
+        unsigned* p = nullptr;
+        const size_t bytes = (size_t)kTailChunkGroups * kTailGroupWords * sizeof(unsigned);
+        bool ok = zero_stream || hipStreamCreateWithFlags(&zero_stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMalloc(&p, bytes) == hipSuccess;
+        ok = ok && hipMemsetAsync(p, 0, bytes, zero_stream) == hipSuccess && hipStreamSynchronize(zero_stream) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (p) (void)hipFree(p);
+            failed = true;
+            return false;
+        }
+        chunks.push_back(p);
+        for (int g = kTailChunkGroups - 1; g >= 0; --g) spare.push_back(p + (size_t)g * kTailGroupWords);
+        groups += kTailChunkGroups;
+        return true;
+    }
 };
-TailBuffers g_tail;
-unsigned* tail_slot(hipStream_t s, int sets = 1) {   // `sets` consecutive counter sets (fused launches: one per body)
+TailPool g_tail[64];
+std::atomic<int> g_tail_check{[] { const char* e = getenv("FEINSUM_TAIL_CHECK"); return e && e[0] == '1' ? 1 : 0; }()};
+
+uintptr_t tail_stream_key(hipStream_t s) {
+    if (s == hipStreamPerThread) {   // one handle value, a different stream in every thread
+        static thread_local char marker;
+        return reinterpret_cast<uintptr_t>(&marker) | 1u;
+    }
+    return reinterpret_cast<uintptr_t>(s);
+}
+
+// counts (and clears) the non-zero words of a group; the caller has made sure nothing is running on it
+int tail_group_dirty(unsigned* group, bool repair, long long* dirty) {
+    static thread_local std::vector<unsigned> host;
+    host.resize(kTailGroupWords);
+    FE_HIP_CHECK(hipMemcpy(host.data(), group, kTailGroupWords * sizeof(unsigned), hipMemcpyDeviceToHost));
+    long long n = 0;
+    for (unsigned w : host) n += w != 0;
+    if (n && repair) FE_HIP_CHECK(hipMemset(group, 0, kTailGroupWords * sizeof(unsigned)));
+    *dirty += n;
+    return FE_OK;
+}
+
+// The counters for a launch on stream `s` that needs `sets` consecutive sets; null = walk statically.
+unsigned* tail_slot(hipStream_t s, int sets = 1) {
     int dev = 0;
+    if (sets < 1 || sets > kTailSetsPerGroup) return nullptr;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!g_tail.base[dev].load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> guard(g_tail.lock);
-        if (!g_tail.base[dev].load(std::memory_order_relaxed) && !g_tail.failed[dev]) {
-            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-                (void)hipGetLastError();
-                return nullptr;   // try again at the next launch outside a capture
-            }
-            unsigned* p = nullptr;
-            const size_t bytes = (size_t)kTailSlots * fe::kTailWords * sizeof(unsigned);
-            if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                g_tail.failed[dev] = true;
-                return nullptr;
-            }
-            g_tail.base[dev].store(p, std::memory_order_release);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    TailPool& pool = g_tail[dev];
+    std::lock_guard<std::mutex> guard(pool.lock);
+    if (st != hipStreamCaptureStatusNone) {   // a graph node: a group of its own, never handed out again
+        if (pool.spare.empty()) return nullptr;
+        unsigned* g = pool.spare.back();
+        pool.spare.pop_back();
+        ++pool.captured;
+        return g;
+    }
+    const uintptr_t key = tail_stream_key(s);
+    auto it = pool.by_stream.find(key);
+    if (it == pool.by_stream.end()) {
+        // keep a chunk's worth of spares behind the eager streams, so that a later capture finds some
+        if (pool.spare.size() <= 1 && !pool.grow() && pool.spare.empty()) return nullptr;
+        unsigned* g = pool.spare.back();
+        pool.spare.pop_back();
+        it = pool.by_stream.emplace(key, g).first;
+    }
+    if (g_tail_check.load(std::memory_order_relaxed)) {   // debugging aid: the group must be zero once the stream is idle
+        long long dirty = 0;
+        if (hipStreamSynchronize(s) != hipSuccess || tail_group_dirty(it->second, true, &dirty) != FE_OK || dirty) {
+            fprintf(stderr, "feinsum_hip: ticket counters of stream %p held %lld non-zero words before a launch (repaired)\n",
+                    (void*)s, dirty);
         }
     }
-    unsigned* const base = g_tail.base[dev].load(std::memory_order_acquire);
-    if (!base || sets < 1 || sets > 4) return nullptr;
-    // slots are handed out in groups of four, so that a launch with up to four counter sets has them side by side
-    const unsigned group = g_tail.next[dev].fetch_add(1) % (kTailSlots / 4);
-    return base + (size_t)group * 4 * fe::kTailWords;
+    return it->second;
 }
-// Number of statically walked tiles of a launch of `waves` waves: two rounds, the rest by tickets (FEINSUM_TAIL_ROUNDS /
-// fe_set_tail_rounds: at most so many full rounds by tickets; negative: none); launches of fewer than five rounds walk
-// statically (E = 1e5 on 2048 waves: three rounds, measured slower with tickets).
+// Number of statically walked tiles of a launch of `blocks` blocks of `waves / blocks` waves: two rounds, the rest by
+// tickets (FEINSUM_TAIL_ROUNDS / fe_set_tail_rounds: at most so many full rounds by tickets; negative: none); launches of
+// fewer than five rounds walk statically (E = 1e5 on 2048 waves: three rounds, measured slower with tickets), and so do
+// grids of fewer than 8 blocks per pool: a block's pool is (bid / 8) % kTailPools and nobody steals, so that a pool
+// without blocks would keep its tiles (a 32-CU partition launches 64 blocks).
 std::atomic<int> g_tail_rounds{[] { const char* e = getenv("FEINSUM_TAIL_ROUNDS"); return e ? atoi(e) : (1 << 20); }()};
-int64_t tail_static_tiles(int64_t nTiles, int64_t waves) {
+int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock) {
     const int dyn_rounds = g_tail_rounds.load(std::memory_order_relaxed);
-    const int64_t rounds = nTiles / waves;
+    const int64_t waves = blocks * wavesPerBlock;
+    const int64_t rounds = waves > 0 ? nTiles / waves : 0;
+    if (blocks < 8 * fe::kTailPools) return nTiles;
     if (dyn_rounds < 0 || rounds < 5 || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
     int64_t ks = rounds - dyn_rounds;
     if (ks < 2) ks = 2;
     return ks * waves;
 }
+
+// kOpLoadsTemporal (fe_common.h) for a launch that reads `input_bytes`: plain instead of non-temporal loads of the streamed
+// operand while the launch's inputs fit the Infinity Cache ($FEINSUM_TEMPORAL_LOADS_MIB / fe_set_temporal_loads_mib; 0 = never).
+// `min_bytes`: div and face-mass launches of fewer than about three rounds measured 3 - 8 % SLOWER with plain loads (div
+// E = 4e4 ... 8e4, face-mass x 4 E = 2e4 ... 3e4; grad and the fused launches gain or stay level at every small size:
+// profiles/r04/temporal_loads_ab.txt), so those families switch only above a measured floor.
+std::atomic<long long> g_temporal_input_bytes{[] {
+    const char* e = getenv("FEINSUM_TEMPORAL_LOADS_MIB");
+    return e ? (long long)atoll(e) << 20 : fe::kTemporalInputBytes;
+}()};
+int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0) {
+    const long long cap = g_temporal_input_bytes.load(std::memory_order_relaxed);
+    if (cap >= (1ll << 40)) return fe::kOpLoadsTemporal;        // "always" (A/B runs)
+    return input_bytes <= cap && input_bytes >= min_bytes ? fe::kOpLoadsTemporal : 0;
+}
+constexpr int64_t kTemporalFloorDiv = 80ll << 20, kTemporalFloorFaceMass = 64ll << 20;
 
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
@@ -256,7 +351,7 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
 #endif
     const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
-        const int64_t t_static = tail_static_tiles(nTiles, (int64_t)grid * G::WAVES);
+        const int64_t t_static = tail_static_tiles(nTiles, grid, G::WAVES);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
@@ -379,6 +474,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
+    opT |= temporal_flag((9 + (int64_t)nb * NP) * E * 8);
     static PerDeviceOnce once_plain, once_prepared, once_planes;
     char what[64];
     const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
@@ -399,6 +495,9 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
         if (NP == 35) {
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 1>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 4>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 16>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 20>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
@@ -423,6 +522,9 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
         case 2: FE_GRAD_CASE(2); break;
+        case 4: FE_GRAD_CASE(4); break;     // temporal stores
+        case 16: FE_GRAD_CASE(16); break;   // temporal loads
+        case 20: FE_GRAD_CASE(20); break;   // both
         case 32:
             if (gsec) {
                 hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
@@ -430,7 +532,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                 break;
             }
             if (nb == 1) {   // per-wave time stamps of the dynamic walk
-                const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                const int64_t t_static = tail_static_tiles(nTiles, g.x, G::WAVES);
                 unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                 if (tail) {
                     static PerDeviceOnce once_stamps;
@@ -453,7 +555,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             }
             {
                 {   // behind two static rounds the tiles come by tickets (fe_common.h: dynamic walk); any number of fields
-                    const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                    const int64_t t_static = tail_static_tiles(nTiles, g.x, G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
@@ -488,6 +590,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
+    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv);
     static PerDeviceOnce once_plain, once_prepared;
     char what[64];
     int attr_rc;
@@ -530,7 +633,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             }
             {
                 if (!(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h); any number of fields
-                    const int64_t t_static = tail_static_tiles(nTiles, (int64_t)g.x * G::WAVES);
+                    const int64_t t_static = tail_static_tiles(nTiles, g.x, G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
@@ -617,6 +720,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
     constexpr bool kCanPrep = !ALDS && NF == fe::kFmNf;   // prepared operators: tetrahedra p = 1..4
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
+    jfe = (jfe ? 1 : 0) | temporal_flag((NF + (int64_t)NB * NF * NFP) * E * 8, kTemporalFloorFaceMass);
     static PerDeviceOnce once_plain, once_prepared;
     char what[96];
     int attr_rc = FE_OK;
@@ -645,7 +749,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
         }
     }
     if constexpr (NP == 56 && NFP == 21 && M == 1 && NF == fe::kFmNf && ALDS && NB == 4) {
-        const int64_t t_static = tail_static_tiles(nTiles, blocks * G::WAVES);
+        const int64_t t_static = tail_static_tiles(nTiles, blocks, G::WAVES);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
@@ -659,7 +763,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     }
     if constexpr (NF == fe::kFmNf && !ALDS && (NB == 3 || NB == 4)) {   // tetrahedra p = 1 .. 4
         // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
-        const int64_t t_static = tail_static_tiles(nTiles, blocks * G::WAVES);
+        const int64_t t_static = tail_static_tiles(nTiles, blocks, G::WAVES);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
@@ -799,13 +903,13 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     const unsigned grid = persistent_grid(nTiles, 4);
     fe::FusedTail ft = {nullptr, nTilesD, nTilesG, 0};
     if (kDyn && !prep) {
-        ft.static_d = tail_static_tiles(nTilesD, (int64_t)grid * 4);
-        ft.static_g = tail_static_tiles(nTilesG, (int64_t)grid * 4);
+        ft.static_d = tail_static_tiles(nTilesD, grid, 4);
+        ft.static_g = tail_static_tiles(nTilesG, grid, 4);
         if (ft.static_d < nTilesD || ft.static_g < nTilesG) ft.tail = tail_slot(s, 2);
     }
     // body order (fe_fused.h): with the static walk the younger half of the grid runs grad first; with tickets every block
     // runs div, then grad (profiles/r03/dynamic_walk_fused.txt: 77.9 - 78.1 against 76.9 - 77.6 %)
-    int op_arg = (ft.tail ? 0 : kFusedOrderGradDiv) << 8;
+    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8);
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
 #endif
@@ -840,12 +944,13 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
     const unsigned grid = persistent_grid(nTiles, 4);
     fe::FusedTail ft = {nullptr, a.nTilesD, a.nTilesG, a.nTilesF};
     if (kDyn && !(a.prepD && a.prepR)) {
-        ft.static_d = tail_static_tiles(a.nTilesD, (int64_t)grid * 4);
-        ft.static_g = tail_static_tiles(a.nTilesG, (int64_t)grid * 4);
-        ft.static_f = NB >= 3 ? tail_static_tiles(a.nTilesF, (int64_t)grid * 4) : a.nTilesF;
+        ft.static_d = tail_static_tiles(a.nTilesD, grid, 4);
+        ft.static_g = tail_static_tiles(a.nTilesG, grid, 4);
+        ft.static_f = NB >= 3 ? tail_static_tiles(a.nTilesF, grid, 4) : a.nTilesF;
         if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
     }
     fe::WaveOpArgs args = a;
+    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8);
     if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);
@@ -1079,14 +1184,19 @@ int fe_split_alloc(void** ptr, size_t bytes, int32_t flags) {
 
 int fe_split_free(void* ptr) {
     if (!ptr) return FE_OK;
-    SplitPool* pool = split_pool_of_current_device();
+    const int dev = split_owner_device(ptr);
+    if (dev < 0) return fail(FE_EINVAL, "fe_split_free: %p is not an array of the split allocator (on any device)", ptr);
+    SplitDeviceScope scope(dev);
+    SplitPool* pool = &g_split_pools[dev];
     std::lock_guard<std::mutex> lock(pool->mu);
     return pool->free_array(ptr);
 }
 
 int fe_split_info(const void* ptr, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0) return fail(FE_EINVAL, "fe_split_info: no buffer");
-    SplitPool* pool = split_pool_of_current_device();
+    const int dev = split_owner_device(ptr);
+    if (dev < 0) return fail(FE_EINVAL, "fe_split_info: %p is not an array of the split allocator (on any device)", ptr);
+    SplitPool* pool = &g_split_pools[dev];
     std::lock_guard<std::mutex> lock(pool->mu);
     return pool->info(ptr, buf, buf_len);
 }
@@ -1821,6 +1931,11 @@ int fe_dbg_read_w8(unsigned long long* out, int n_waves) {
     FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_w8), (size_t)n_waves * 64));
     return FE_OK;
 }
+int fe_dbg_read_phase(unsigned long long* out, int n_waves) {
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_phase), (size_t)n_waves * 32));
+    return FE_OK;
+}
 int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
     FE_HIP_CHECK(hipDeviceSynchronize());
     FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_stamps), (size_t)n_waves * 32));
@@ -1831,6 +1946,62 @@ int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
 int fe_set_tail_rounds(int32_t rounds) {
     const int before = g_tail_rounds.exchange(rounds);
     return before;
+}
+
+int fe_set_temporal_loads_mib(int32_t mib) {
+    return (int)(g_temporal_input_bytes.exchange(mib < 0 ? 0 : (long long)mib << 20) >> 20);
+}
+
+int fe_set_cu_limit(int32_t cus) {
+    return g_cu_limit.exchange(cus < 0 ? 0 : cus);
+}
+
+int fe_stream_retired(void* stream) {
+    int dev = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FE_EINVAL, "fe_stream_retired: device %d", dev);
+    TailPool& pool = g_tail[dev];
+    std::lock_guard<std::mutex> guard(pool.lock);
+    auto it = pool.by_stream.find(tail_stream_key(static_cast<hipStream_t>(stream)));
+    if (it == pool.by_stream.end()) return 0;
+    pool.spare.push_back(it->second);   // zero, like every group between launches
+    pool.by_stream.erase(it);
+    return 1;
+}
+
+int fe_tail_plant(void* stream, uint32_t value) {
+    int dev = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FE_EINVAL, "fe_tail_plant: device %d", dev);
+    unsigned* group = nullptr;
+    {
+        TailPool& pool = g_tail[dev];
+        std::lock_guard<std::mutex> guard(pool.lock);
+        auto it = pool.by_stream.find(tail_stream_key(static_cast<hipStream_t>(stream)));
+        if (it == pool.by_stream.end()) return fail(FE_EINVAL, "fe_tail_plant: the stream owns no counter group (no dynamic launch yet)");
+        group = it->second;
+    }
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpy(group + 3 * fe::kTailStride, &value, sizeof(value), hipMemcpyHostToDevice));   // pool 3's ticket counter
+    return FE_OK;
+}
+
+int fe_tail_check(int32_t repair, int64_t* dirty_words, int32_t* groups, int32_t* streams, int32_t* captured) {
+    int dev = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FE_EINVAL, "fe_tail_check: device %d", dev);
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    TailPool& pool = g_tail[dev];
+    std::lock_guard<std::mutex> guard(pool.lock);
+    long long dirty = 0;
+    for (unsigned* chunk : pool.chunks)
+        for (int g = 0; g < kTailChunkGroups; ++g)
+            if (int rc = tail_group_dirty(chunk + (size_t)g * kTailGroupWords, repair != 0, &dirty)) return rc;
+    if (dirty_words) *dirty_words = dirty;
+    if (groups) *groups = pool.groups;
+    if (streams) *streams = (int32_t)pool.by_stream.size();
+    if (captured) *captured = pool.captured;
+    return FE_OK;
 }
 
 int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {

@@ -27,9 +27,9 @@ Argument conventions kept from the reference:
                matrices; ``"placement"`` (or ``$FEINSUM_PLACEMENT``): ``timeit``
                allocates one array per operand as the reference does; with the
                default ``"split"`` the outputs come from the split allocator
-               (``feinsum_amd.placement.zeros``), ``"separate"`` takes every array
-               from torch, ``"tuned"`` (opt-in) scans an arena for the fastest
-               position; ``timeit_details(...).placement`` reports which was used.
+               (``feinsum_amd.placement.zeros``; ``evaluate`` allocates the outputs it
+               is not handed the same way), ``"separate"`` takes every array
+               from torch; ``timeit_details(...).placement`` reports which was used.
 ``schedule``   accepted and ignored: the kernels implement the optimal schedule.
 
 Inputs are drawn from ``numpy.random.default_rng(0)`` in **sorted argument-name
@@ -471,13 +471,16 @@ def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
         _check_tensor(name, arg_dict[name], concrete, einsum.arg_to_dtype[name], q)
     out_shape = tuple(sizes[d.name] if isinstance(d, SizeParam) else int(d) for d in einsum.shape)
     outs = []
+    allocated: dict = {}      # outputs this call allocated itself: name -> "split" | "torch" | "torch (<why>)"
     for k, name in enumerate(einsum.output_names):
         dt = result_dtype(einsum, k)
         if out_dict is not None and name in out_dict:
             _check_tensor(name, out_dict[name], out_shape, dt, q)
             outs.append(out_dict[name])
         else:
-            outs.append(torch.empty(out_shape, dtype=getattr(torch, dt.name), device=q.torch_device))
+            tensor, how = _allocate_output(out_shape, getattr(torch, dt.name), q.torch_device, transform)
+            outs.append(tensor)
+            allocated[name] = how
     plan = match_family(einsum)
     variant = _variant_from_transform(transform)
     if plan is not None:
@@ -495,7 +498,33 @@ def _bind(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any],
     span = lambda t: (int(t.data_ptr()), int(t.numel()) * int(t.element_size()))   # noqa: E731
     bound.reads = tuple(span(arg_dict[name]) for name in sorted(einsum.all_args))
     bound.writes = tuple(span(t) for t in outs)
+    bound.output_allocations = MappingProxyType(allocated)
     return q, bound, outs
+
+
+def _allocate_output(shape: Tuple[int, ...], dtype: Any, device: Any, transform: Any):
+    """
+    An output array the caller did not supply (the reference allocates them through its PyOpenCL pool,
+    ``src/feinsum/measure.py:44-60,236-246``).  Arrays of 8 MiB and more come from the split allocator
+    (``placement.empty``: on MI355X a launch writing into its arrays runs 5-12 % faster than into ordinary allocations,
+    DESIGN.md section 3d) unless ``transform={"placement": "separate"}`` / ``$FEINSUM_PLACEMENT=separate`` asks for plain
+    ones; whatever the allocator cannot serve (no VMM support, address-space cap, out of memory in its pool) is a plain
+    ``torch.empty``.  Returns ``(tensor, how)``.
+    """
+    import torch
+
+    from feinsum_amd import placement
+
+    nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size() if shape else 0
+    if torch.device(device).type != "cuda" or nbytes < placement.SPLIT_MIN_BYTES:
+        return torch.empty(shape, dtype=dtype, device=device), "torch"
+    if _placement_mode(transform) != "split":
+        return torch.empty(shape, dtype=dtype, device=device), "torch (placement: separate)"
+    try:
+        return placement.empty(shape, dtype, device), "split"
+    except (RuntimeError, HipLibraryError) as exc:
+        logger.warning("split allocator not available (%s); the output is an ordinary allocation", str(exc)[:160])
+        return torch.empty(shape, dtype=dtype, device=device), f"torch (split allocator failed: {str(exc)[:120]})"
 
 
 def evaluate(einsum: BatchedEinsum, cq: Any, arg_dict: Mapping[str, Any], *,
@@ -565,7 +594,7 @@ def validate_batched_einsum_transform(einsum: BatchedEinsum, cq: Any, transform:
     logger.info("Statistically verified the soundness of the transformation")
 
 
-PLACEMENT_MODES = ("split", "separate", "tuned")
+PLACEMENT_MODES = ("split", "separate")
 
 
 def _placement_mode(transform: Any) -> str:
@@ -575,12 +604,11 @@ def _placement_mode(transform: Any) -> str:
 
     ``"split"``     one allocation per array, as the reference does (``src/feinsum/measure.py:44-60,80-108``); the
                     OUTPUTS come from the split allocator (``feinsum_amd.placement.zeros``), whose arrays alternate
-                    between two classes of physical memory every 4 MiB -- no arena, no scan, memory = the footprint, and
-                    a caller gets the same arrays for ``evaluate`` with ``placement.empty``.
+                    between two classes of physical memory every 4 MiB -- no arena, no scan, memory = the footprint.
+                    ``evaluate`` allocates the outputs it is not handed the same way, and a caller gets such arrays
+                    with ``placement.empty``.
     ``"separate"``  every array from the torch allocator: the reference's protocol to the letter, and what a caller
                     who allocates with ``torch.empty`` gets.
-    ``"tuned"``     opt-in (round 2): all arrays in one large arena at the position where the launch times fastest
-                    (``placement.tune_base``); its number holds for arrays placed that way only.
     The :class:`TimingResult` says which one was used (``record_facts`` stores it with the fact).
     """
     import os
@@ -602,9 +630,8 @@ class TimingResult:
     seconds_wall: float       # host wall-clock per launch, reference protocol
     rounds: int
     #: how the timed arrays were placed: {"mode": "split", "outputs": the allocator's report per output} (one allocation
-    #: per array, outputs from the split allocator), {"mode": "separate"} (every array from torch) or the report of
-    #: placement.tune_base_retry ({"mode": "tuned", arena size, positions scanned, whether a class boundary was found,
-    #: ...}); a placement that could not be had says so under "fallback"
+    #: per array, outputs from the split allocator) or {"mode": "separate"} (every array from torch); a placement that
+    #: could not be had says so under "fallback"
     placement: Mapping[str, Any] = field(default_factory=lambda: MappingProxyType({"mode": "separate"}))
 
 
@@ -641,38 +668,6 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
     # `transform={"prepared": True}`: the operator matrices are written once in fragment layout (see
     # _FamilyLaunch.prepare_operators) instead of being rebuilt by every launch
     prepare = _prepared_from_transform(transform, False)
-    if mode == "tuned":
-        # the same arrays, moved into one arena at the position where the launch runs fastest (placement.py)
-        from feinsum_amd import placement
-
-        names = sorted(arg_dict)
-        out_names = list(out_dict)
-        arrays = [(n, tuple(arg_dict[n].shape), arg_dict[n].dtype) for n in names] \
-            + [(n, tuple(t.shape), t.dtype) for n, t in out_dict.items()]
-        staged = dict(arg_dict)
-        out_dict = None               # the outputs need no staging (zero-filled views): do not hold them twice
-
-        def fill(name, view):
-            if name in staged:
-                view.copy_(staged[name])
-            else:
-                view.zero_()
-
-        def make_step(views):
-            _, b, _ = _bind(einsum, q, {n: views[n] for n in names}, {n: views[n] for n in out_names}, transform,
-                            prepare=prepare)
-            return lambda n: b.time_batch(n, q.stream_ptr)
-
-        try:
-            with torch.cuda.device(q.torch_device):
-                arena, views, report = placement.tune_base_retry(arrays, q.torch_device, make_step, fill=fill, attempts=2)
-            arg_dict, out_dict = {n: views[n] for n in names}, {n: views[n] for n in out_names}
-        except torch.cuda.OutOfMemoryError as exc:
-            # no room for an arena beside the caller's data: time the separately allocated arrays, and say so
-            logger.warning("tuned placement not available (%s); timing separately allocated arrays", str(exc)[:120])
-            report = {"mode": "separate", "fallback": f"tuned placement asked for, arena allocation failed: {str(exc)[:160]}"}
-            out_dict = generate_out_arrays(q, einsum, long_dim_length)
-        del staged
     _, bound, _ = _bind(einsum, q, arg_dict, out_dict, transform, prepare=prepare)
     with torch.cuda.device(q.torch_device):
         for _ in range(N_WARMUP_ROUNDS):

@@ -175,7 +175,8 @@ def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict
     The optional full-field exchange of SURVEY section 8(e): every rank receives every other rank's shard of every
     output (equal shard lengths; *fields* = ``[(local tensor, element axis)]``).  One ``all_gather_into_tensor`` per
     field on RCCL (gloo: the list form through host memory); only the collectives are between the two fences, the
-    layout copy that brings the element axis to the front is not.  Returns the milliseconds, the bytes each GPU
+    layout copy that brings the element axis to the front is not.  Every rank stages its buffers first and the ranks
+    agree that all of them could (``{"skipped": ...}`` otherwise).  Returns the milliseconds, the bytes each GPU
     received from the others, that rate in GB/s (to be read against 7 xGMI links x 153 GB/s) and ``sums`` = the sum of
     every gathered field (the caller checks them against the all-gathered reductions).
     """
@@ -187,10 +188,20 @@ def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict
     if not in_group():
         raise RuntimeError("allgather_fields_timed needs a process group")
     world = dist.get_world_size()
-    staged = []
-    for local, axis in fields:
-        moved = _comm_tensor(local.movedim(axis, 0).contiguous())
-        staged.append((moved, torch.empty((world,) + tuple(moved.shape), dtype=moved.dtype, device=moved.device)))
+    # stage first, agree, then exchange: a rank that cannot allocate its receive buffers (the likely failure: world x the
+    # shard per field) must not leave the others waiting inside the collective -- every rank learns of it through one
+    # all-reduce of a flag and all of them skip the exchange
+    staged, why = [], ""
+    try:
+        for local, axis in fields:
+            moved = _comm_tensor(local.movedim(axis, 0).contiguous())
+            staged.append((moved, torch.empty((world,) + tuple(moved.shape), dtype=moved.dtype, device=moved.device)))
+    except (RuntimeError, MemoryError) as exc:      # torch.cuda.OutOfMemoryError is a RuntimeError
+        why = f"{type(exc).__name__}: {exc}"[:200]
+        staged = []
+    if not all_agree(not why, fields[0][0].device if fields else None):
+        return {"skipped": "a rank could not stage its receive buffers" + (f" (this rank: {why})" if why else " (another rank)"),
+                "world_size": world}
     barrier()
     sync()
     t0 = time.perf_counter()
@@ -204,6 +215,19 @@ def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict
     received = sum(moved.numel() * moved.element_size() for moved, _ in staged) * (world - 1)
     return {"ms": ms, "bytes_received_per_gpu": received, "gbps_per_gpu": received / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0,
             "sums": [float(full.sum().item()) for _, full in staged], "world_size": world}
+
+
+def all_agree(ok: bool, device: Any = None) -> bool:
+    """True when *ok* holds on EVERY rank (one all-reduce of a flag; every rank must call it)."""
+    import torch
+    import torch.distributed as dist
+
+    if not in_group():
+        return bool(ok)
+    on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
 
 
 def barrier() -> None:

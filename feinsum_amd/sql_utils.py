@@ -12,7 +12,8 @@ read a database written here; what differs is what the columns *mean*:
                       (``xre_rij_ej_to_xei.py``); here it is the name of a kernel
                       variant of ``libfeinsum_hip.so`` (``"mfma"``, ``"generic"``).
 ``transform_params``  what else parametrises the measurement: ``placement`` (how ``timeit`` placed its arrays:
-                      ``"separate"`` = one allocation per array; with ``"tuned"`` also ``placement_report``).
+                      ``"split"`` = outputs from the split allocator, what ``evaluate`` allocates itself;
+                      ``"separate"`` = every array from torch).  ``retrieve`` compares facts of one placement only.
 ``compiler_version``  ``"AMD-ROCm <hip version>"`` instead of the OpenCL vendor/driver.
 keys                  the einsum is keyed by the canonical form of
                       ``feinsum_amd.canonicalization`` (exhaustive search), not by the
@@ -200,7 +201,14 @@ def retrieve(einsum: BatchedEinsum, device: Any, *, database: Union[str, sqlite3
     if not queries:
         raise NoFactInDatabaseError(f"No facts found for the einsum: `{einsum}`, with the filtering"
                                     f" function: {consider_query!r}.")
-    best = max(queries, key=lambda q: sum(q.giga_op_rate(dt) for dt in q.giga_op_info))
+    # Facts taken with different placements of the timed arrays are not comparable (the same kernel is 5-12 % apart between
+    # allocator arrays and torch arrays): variants are ranked within ONE placement -- the one evaluate() uses for the
+    # outputs it allocates ("split") when any fact has it, else the placement with the most facts.
+    by_placement: dict = {}
+    for q in queries:
+        by_placement.setdefault(q.transform_params.get("placement", "separate"), []).append(q)
+    pool = by_placement.get("split") or max(by_placement.values(), key=len)
+    best = max(pool, key=lambda q: sum(q.giga_op_rate(dt) for dt in q.giga_op_info))
     return best.transform
 
 
@@ -272,14 +280,11 @@ def record_facts(einsum: BatchedEinsum, cq: Any, variant: str = "mfma",
                                 long_dim_length=long_dim_length)
         runtime_in_sec = timing.seconds_device
         # how the timed arrays were placed is part of the fact (transform_params is the reference's JSON column for
-        # what parametrises a measurement): "separate" = one allocation per array, what evaluate() callers get
+        # what parametrises a measurement): "split" = outputs from the split allocator (what evaluate() allocates itself),
+        # "separate" = every array from torch (what a caller who hands in torch.empty outputs gets)
         params["placement"] = timing.placement.get("mode", "separate")
         if timing.placement.get("fallback"):
             params["placement_fallback"] = timing.placement["fallback"]
-        if timing.placement.get("mode") == "tuned":
-            params["placement_report"] = {k: timing.placement[k] for k in
-                                          ("class_boundary_found", "arenas_tried", "scan_positions", "scan_median_ms", "best_ms")
-                                          if k in timing.placement}
         device_name = device_name or _as_queue(cq).device.name
     if device_name is None:
         raise ValueError("device_name is needed with an external runtime_in_sec")

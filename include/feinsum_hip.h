@@ -376,6 +376,43 @@ int fe_launch_f32(int32_t family, const fe_argpack* args, void* stream);
  * A tuning knob: results do not depend on it (every tile's arithmetic is position independent). */
 int fe_set_tail_rounds(int32_t rounds);
 
+/* Who owns ticket counters (the re-entrancy contract of SURVEY 8(b): no launch shares mutable state with a launch that can
+ * run beside it).  A launch's counters are zero before and after it, so only launches the device serialises share them:
+ * an eager launch uses the counter group of its STREAM (the per-thread default stream: of its thread), a launch recorded
+ * during stream capture gets a group of its own for the life of the process (the graph may be replayed beside anything).
+ * Any number of streams, driven from any number of host threads, may launch at the same time.  Groups (0.56 MB) are
+ * allocated on demand outside capture, at most 256 per device; a launch that finds none walks statically (same results).
+ *   fe_stream_retired  a stream was destroyed (its launches have completed): its group may serve another stream.
+ *                      Returns 1 if the stream had one, 0 if not.  Optional -- without it the group stays with the handle.
+ *   fe_tail_check      waits for the current device, then counts the non-zero words in all counter groups (there must be
+ *                      none: a launch that did not run to completion would leave some, and later launches through that
+ *                      group would skip tiles) and, with `repair`, zeroes them.  Also reports the groups allocated, the
+ *                      streams that own one and the groups given to captured launches (any out pointer may be NULL).
+ *                      FEINSUM_TAIL_CHECK=1 runs the same check on the launch's group before every dynamic launch
+ *                      (synchronises the stream: a debugging aid).
+ * The reference's executor is single-queue (src/feinsum/measure.py:163-165,243-251); no counterpart. */
+int fe_stream_retired(void* stream);
+int fe_tail_check(int32_t repair, int64_t* dirty_words, int32_t* groups, int32_t* streams, int32_t* captured);
+/* Test hook: waits for the device and writes `value` into one ticket counter of the group `stream` owns (FE_EINVAL if it
+ * owns none) -- the state an interrupted launch would leave behind; tests/test_gpu_streams.py shows fe_tail_check finding
+ * and repairing it. */
+int fe_tail_plant(void* stream, uint32_t value);
+
+/* Loads of the streamed operand (u / v) are non-temporal -- every byte is read once per launch -- unless the launch's inputs
+ * are at most `mib` MiB (default 248, also FEINSUM_TEMPORAL_LOADS_MIB; 0 = never): then they are plain loads that may stay in
+ * the 256 MiB Infinity Cache, where the next launch on the same arrays finds them (grad at the reference's default E = 1e5,
+ * src/feinsum/measure.py:202: 24.8 -> 23.1 us; above the cache size plain loads cost 7-12 %; div and face-mass launches
+ * switch only above 80 / 64 MiB of inputs, below which plain loads measured slower; 1048576 or more = always, for A/B runs).  Stores are non-temporal at every
+ * size.  Applies to the MFMA kernels of the orders p = 1..4 (float64).  Returns the previous setting.  Results do not depend
+ * on it. */
+int fe_set_temporal_loads_mib(int32_t mib);
+
+/* Size the persistent grids as if the device had `cus` compute units (0 = what the device reports; also
+ * FEINSUM_CU_LIMIT).  MI355X partitions report 32 (CPX) or 64 (QPX) CUs: grids of fewer than 128 blocks walk statically
+ * (a ticket pool is drained by the blocks b with (b / 8) % 16 == pool).  Returns the previous limit.  Results do not
+ * depend on it. */
+int fe_set_cu_limit(int32_t cus);
+
 /* Enqueue n_launches back-to-back launches of `family` on `stream`, bracketed
  * by HIP events recorded on that same stream; blocks until the last one is
  * done and returns the elapsed milliseconds of the whole batch in *ms_out.

@@ -71,6 +71,29 @@ def test_a_failing_rank_fails_the_run_and_stops_the_others(tmp_path):
     assert "rank 1 exited with 7" in err.getvalue()
 
 
+def test_a_rank_that_fails_behind_the_line_cannot_take_the_line_with_it(tmp_path):
+    """The optional full-field gather runs AFTER rank 0 has printed the JSON line (bench.py --gather-fields on): one rank
+    raising inside it while the others wait in the collective still leaves the relayed line, and the parent ends the
+    waiting ranks and exits 1 within seconds -- deterministically (VERDICT r03, next #6)."""
+    script = _stub(tmp_path, """
+        import json, os, sys, time
+        rank = int(os.environ["RANK"])
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"])}), flush=True)
+        time.sleep(0.3)                      # every rank is behind the line now
+        if rank == 2:
+            raise RuntimeError("out of memory while staging the receive buffers")
+        time.sleep(120)                      # the others wait inside the collective
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(4, [], script=script, out=out, err=err, timeout_s=100)
+    assert rc == 1 and time.monotonic() - t0 < 30
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 4
+    assert "rank 2 exited with 1" in err.getvalue()
+
+
 def test_timeout_stops_the_ranks(tmp_path):
     script = _stub(tmp_path, "import time; time.sleep(120)")
     err = io.StringIO()

@@ -1,0 +1,239 @@
+"""
+The re-entrancy contract of the C ABI ("distinct streams may be driven from distinct threads", the
+executor contract of src/feinsum/measure.py:163-165,243-251) for the one piece of mutable device state the launchers
+have -- the ticket counters of the dynamic walk (feinsum_amd/csrc/fe_common.h).  A counter group belongs to a STREAM
+(launches on one stream are serialised) or, for a launch recorded during stream capture, to the graph node; launches that
+can run at the same time never share one.  Two launches drawing tickets from one counter would each skip the tiles the
+other took -- silently -- so every check here is bitwise against the static walk, which needs no state.
+"""
+
+import threading
+
+import pytest
+
+import dg
+import feinsum_amd as f
+from feinsum_amd import _hip, measure
+
+E = 200_000        # 12 500 tiles on 2048 waves: six rounds, four of them by tickets
+
+
+def _inputs(torch, expr, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return {a: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[a]),
+                          dtype=torch.float64, device="cuda", generator=g) for a in sorted(expr.all_args)}
+
+
+@pytest.fixture(scope="module")
+def cases():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    exprs = {"grad": dg.grad(), "div": dg.div(), "face_mass": dg.face_mass(4)}
+    devs = {k: _inputs(torch, e, 11 + i) for i, (k, e) in enumerate(exprs.items())}
+    before = _hip.set_tail_rounds(-1)          # the static walk: the reference bits
+    try:
+        static = {k: {n: t.clone() for n, t in f.evaluate(exprs[k], 0, devs[k], wait=True).items()} for k in exprs}
+    finally:
+        _hip.set_tail_rounds(before)
+    return torch, exprs, devs, static
+
+
+def _outputs(torch, expr):
+    shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+    return {n: torch.full(shape, float("nan"), dtype=torch.float64, device="cuda") for n in expr.output_names}
+
+
+@pytest.mark.gpu
+def test_two_threads_two_streams_forty_launches_each(cases):
+    """Two host threads, one stream each, forty alternating grad / div / face-mass launches per thread, nothing waited for
+    in between: more launches in flight than the sixteen counter groups round 3 handed out in turn (launch k and launch
+    k + 16 then shared counters).  Every launch writes its own output arrays; all of them hold the static walk's bits."""
+    torch, exprs, devs, static = cases
+    names = list(exprs)
+    results, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            q = f.DeviceQueue(0, stream=stream)
+            bound = []
+            for k in range(40):
+                name = names[(k + tid) % 3]
+                outs = _outputs(torch, exprs[name])
+                bound.append((name, outs, measure._bind(exprs[name], q, devs[name], outs, None)[1]))
+            stream.wait_stream(torch.cuda.current_stream())      # (the NaN fills ran on the thread's current stream)
+            start.wait()
+            with torch.cuda.device(0):
+                for _, _, b in bound:
+                    b.launch(q.stream_ptr)
+            stream.synchronize()
+            results[tid] = [(name, outs) for name, outs, _ in bound]
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+            start.abort()
+
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        _hip.set_tail_rounds(before)
+    assert not errors, errors
+    for tid in (0, 1):
+        for k, (name, outs) in enumerate(results[tid]):
+            for n, t in outs.items():
+                assert torch.equal(t, static[name][n]), (tid, k, name, n)
+    check = _hip.tail_check()
+    assert check["dirty_words"] == 0 and check["streams"] >= 2, check
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [True, False])
+def test_graph_replays_beside_eager_launches(cases, fuse):
+    """A captured operator (div + grad + face-mass x 4: one fused launch with a counter set per body, or three launches)
+    replayed on stream A while eager launches of the same families run on stream B: the graph's launches own their
+    counters for good, so neither side disturbs the other."""
+    torch, exprs, devs, static = cases
+    shared = dict(devs["grad"])                                    # div and grad of one operator share J and D
+    ddev = dict(devs["div"], J=shared["J"], R=shared["R"])
+    stages = [(exprs["div"], ddev), (exprs["grad"], shared), (exprs["face_mass"], devs["face_mass"])]
+    before = _hip.set_tail_rounds(-1)
+    try:
+        ref = [{n: t.clone() for n, t in od.items()} for od in f.evaluate_operator(stages, 0, fuse=fuse, wait=True)]
+        _hip.set_tail_rounds(1 << 20)
+        outs_graph = [_outputs(torch, e) for e, _ in stages]
+        op = f.bind_operator(stages, 0, out_dicts=outs_graph, fuse=fuse)
+        assert len(op.launches) == (1 if fuse else 3)
+        op.capture()
+        for od in outs_graph:                                      # (capture() ran the operator once: start from NaN again)
+            for t in od.values():
+                t.fill_(float("nan"))
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Stream(), torch.cuda.Stream()
+        qb = f.DeviceQueue(0, stream=b)
+        eager = []
+        for k in range(24):
+            name = list(exprs)[k % 3]
+            outs = _outputs(torch, exprs[name])
+            eager.append((name, outs, measure._bind(exprs[name], qb, devs[name], outs, None)[1]))
+        torch.cuda.synchronize()
+        for rep in range(8):
+            with torch.cuda.stream(a):
+                op.replay()
+            with torch.cuda.device(0):
+                for name, outs, bnd in eager[3 * rep:3 * rep + 3]:
+                    bnd.launch(qb.stream_ptr)
+        torch.cuda.synchronize()
+    finally:
+        _hip.set_tail_rounds(before)
+    for k, od in enumerate(outs_graph):
+        for n, t in od.items():
+            assert torch.equal(t, ref[k][n]), ("graph", fuse, k, n)
+    for k, (name, outs, _) in enumerate(eager):
+        for n, t in outs.items():
+            assert torch.equal(t, static[name][n]), ("eager", fuse, k, name, n)
+    check = _hip.tail_check()
+    assert check["dirty_words"] == 0 and check["captured"] >= 1, check
+
+
+@pytest.mark.gpu
+def test_a_stream_keeps_its_group_and_a_retired_stream_gives_it_back(cases):
+    torch, exprs, devs, static = cases
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        s1 = torch.cuda.Stream()
+        q1 = f.DeviceQueue(0, stream=s1)
+        n0 = _hip.tail_check()["streams"]
+        for _ in range(3):
+            f.evaluate(exprs["grad"], q1, devs["grad"], wait=True)
+        assert _hip.tail_check()["streams"] == n0 + 1                 # one group per stream, however many launches
+        assert _hip.stream_retired(int(s1.cuda_stream)) is True
+        assert _hip.stream_retired(int(s1.cuda_stream)) is False
+        assert _hip.tail_check()["streams"] == n0
+        out = f.evaluate(exprs["grad"], q1, devs["grad"], wait=True)["_fe_out"]     # ... and takes one again when it launches
+        assert torch.equal(out, static["grad"]["_fe_out"])
+    finally:
+        _hip.set_tail_rounds(before)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cus", [32, 64, 100])
+def test_small_grids_walk_statically(cases, cus):
+    """A 32-CU (CPX) or 64-CU (QPX) partition of MI355X launches 64 / 128 blocks -- half of that for the eight-wave p = 5
+    kernels: below 128 blocks some of the sixteen ticket pools have no block to drain them (a block's pool is (bid / 8)
+    mod 16, nobody steals), and round 3 left their tiles unwritten.  fe_set_cu_limit sizes the grids as such a
+    device would; outputs are pre-filled with NaN; the reference bits are those of the full grid."""
+    torch, exprs, devs, static = cases
+    more = {"grad_p5": dg.grad(56), "face_mass_p5": dg.face_mass(4, 56, 4, 21)}
+    mdev = {k: _inputs(torch, e, 31 + i) for i, (k, e) in enumerate(more.items())}
+    before_rounds = _hip.set_tail_rounds(1 << 20)
+    try:
+        full = {k: {n: t.clone() for n, t in f.evaluate(more[k], 0, mdev[k], wait=True).items()} for k in more}
+        before_cus = _hip.set_cu_limit(cus)
+        try:
+            for name, expr in list(exprs.items()) + list(more.items()):
+                outs = _outputs(torch, expr)
+                f.evaluate(expr, 0, (devs if name in devs else mdev)[name], out_dict=outs, wait=True)
+                for n, t in outs.items():
+                    assert torch.equal(t, (static if name in static else full)[name][n]), (cus, name, n)
+        finally:
+            assert _hip.set_cu_limit(before_cus) == cus
+    finally:
+        _hip.set_tail_rounds(before_rounds)
+    assert _hip.tail_check()["dirty_words"] == 0
+
+
+@pytest.mark.gpu
+def test_tail_check_finds_and_repairs_a_stale_counter(cases):
+    """The invariant every dynamic launch relies on -- counters are zero between launches -- is checkable and repairable
+    (a launch that did not run to completion would leave tickets behind, and later launches through that group would skip
+    tiles: ADVICE r03).  A stale ticket is planted by hand in the default stream's group."""
+    torch, exprs, devs, static = cases
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        f.evaluate(exprs["grad"], 0, devs["grad"], wait=True)
+        assert _hip.tail_check()["dirty_words"] == 0
+        _hip.tail_plant(int(torch.cuda.current_stream().cuda_stream), 5)
+        assert _hip.tail_check()["dirty_words"] == 1
+        assert _hip.tail_check(repair=True)["dirty_words"] == 1      # reports what it found, then zeroes it
+        assert _hip.tail_check()["dirty_words"] == 0
+        out = f.evaluate(exprs["grad"], 0, devs["grad"], wait=True)["_fe_out"]
+        assert torch.equal(out, static["grad"]["_fe_out"])
+    finally:
+        _hip.set_tail_rounds(before)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["grad", "div", "face_mass", "pipeline"])
+def test_plain_and_non_temporal_loads_give_the_same_bits(cases, name):
+    """Launches whose inputs fit the Infinity Cache fetch their streamed operand with plain instead of non-temporal loads
+    (fe_set_temporal_loads_mib; feinsum_amd/csrc/fe_common.h): a cache hint, not arithmetic -- the same bits either way, for
+    the single launches and for the fused operator (one launch, three bodies)."""
+    torch, exprs, devs, static = cases
+    if name == "pipeline":
+        shared = dict(devs["grad"])
+        stages = [(exprs["div"], dict(devs["div"], J=shared["J"], R=shared["R"])), (exprs["grad"], shared),
+                  (exprs["face_mass"], devs["face_mass"])]
+    else:
+        stages = [(exprs[name], devs[name])]
+    before = _hip.set_temporal_loads_mib(0)
+    try:
+        results = []
+        for mib in (0, 1 << 20, 248):
+            _hip.set_temporal_loads_mib(mib)
+            results.append([{n: t.clone() for n, t in od.items()} for od in f.evaluate_operator(stages, 0, wait=True)])
+        for other in results[1:]:
+            for od, rd in zip(other, results[0]):
+                for n in rd:
+                    assert torch.equal(od[n], rd[n]), (name, n)
+        if name != "pipeline":
+            for n, t in results[0][0].items():
+                assert torch.equal(t, static[name][n])
+    finally:
+        assert _hip.set_temporal_loads_mib(before) == 248

@@ -121,11 +121,17 @@ static int ab_main(int argc, char** argv) {
                     FILE* f = fopen(getenv("FE_DUMP_STAMPS"), "w");
                     unsigned long long tmin = ~0ull;
                     for (int w = 0; w < 2048; ++w) tmin = std::min(tmin, st4[4 * w]);
-                    fprintf(f, "wave,xcc,hw_id,entry_us,loop_start_us,loop_end_us,tiles\n");
-                    for (int w = 0; w < 2048; ++w)
-                        fprintf(f, "%d,%llu,%llu,%.2f,%.2f,%.2f,%llu\n", w, st4[4 * w + 3] & 0xff, (st4[4 * w + 3] >> 8) & 0xffffffffull,
+                    std::vector<unsigned long long> ph(2048 * 4, 0);
+                    st_fn rp = (st_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_phase");
+                    if (rp) rp(ph.data(), 2048);
+                    fprintf(f, "wave,xcc,hw_id,entry_us,loop_start_us,loop_end_us,tiles,op_landed_us,barrier1_us,frags_built_us,barrier2_us\n");
+                    for (int w = 0; w < 2048; ++w) {
+                        fprintf(f, "%d,%llu,%llu,%.2f,%.2f,%.2f,%llu", w, st4[4 * w + 3] & 0xff, (st4[4 * w + 3] >> 8) & 0xffffffffull,
                                 (st4[4 * w] - tmin) / 100.0, (st4[4 * w + 1] - tmin) / 100.0, (st4[4 * w + 2] - tmin) / 100.0,
                                 st4[4 * w + 3] >> 40);
+                        for (int k = 0; k < 4; ++k) fprintf(f, ",%.2f", ph[4 * w + k] >= tmin ? (ph[4 * w + k] - tmin) / 100.0 : -1.0);
+                        fprintf(f, "\n");
+                    }
                     fclose(f);
                 }
                 unsigned long long t0 = ~0ull, e_max = 0, l_min = ~0ull, l_max = 0, end_min = ~0ull, end_max = 0;
