@@ -278,9 +278,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
 
         // ---- A fragments from the staged operator (addresses = row part + column part: the 63
         //      fragments of p = 4 cost one add and one LDS read each)
-#ifdef FE_BUILD_PRIO
-        if (FE_BUILD_PRIO == 2 || bid >= (nblk + 1) / 2) __builtin_amdgcn_s_setprio(3);
-#endif
         const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
         const int gp = n & 3, q = n >> 2;
         const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
@@ -309,9 +306,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fe_dbg_phase[bid * G::WAVES + wave][2] = __builtin_amdgcn_s_memrealtime();
         }
-#endif
-#ifdef FE_BUILD_PRIO
-        __builtin_amdgcn_s_setprio(0);
 #endif
         __syncthreads();   // the staging area becomes the waves' output buffers
 #ifdef FE_EXPERIMENTS
