@@ -125,8 +125,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
     const GradFields* __restrict__ Q = nullptr, unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
-    static_assert(!kDyn || (MODE == 0 && ND == 3 && !ALDS && !W8 && !kPrep) || (MODE == 4 && ND == 3 && W8),
-                  "dynamic walk: plain div of tetrahedra, or the eight-wave grad by components (p = 5)");
+    static_assert(!kDyn || ((MODE == 0 || MODE == 4) && !ALDS && !W8 && !kPrep) || (MODE == 4 && ND == 3 && W8),
+                  "dynamic walk: div (tetrahedra, triangles), grad by components (triangles), or the eight-wave grad by components (p = 5)");
     // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
@@ -894,6 +894,15 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_ke
     unsigned* __restrict__ tail, int64_t t_static) {
     div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, kBatched ? nb : 1, E, nTiles, opT, 0, blockIdx.x,
                                                                 gridDim.x, nullptr, tail, t_static);
+}
+
+// triangles (ND = 2) with a dynamic walk: div (MODE 0) and grad by components (MODE 4), any number of fields
+template <int NP, int M, int MODE>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void nd2_mfma_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    div3d_mfma_body<NP, M, 0, MODE, 2, false, false, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
+                                                                  tail, t_static);
 }
 
 // grad by components in eight-wave blocks (p = 5) with a dynamic walk (nb is a run-time argument although the launcher passes

@@ -482,12 +482,12 @@ __global__ __launch_bounds__(512, 1) FE_TAIL_KERNEL_ATTR void facemass_w8_tail_k
 }
 
 // the launch of fields in registers with a dynamic walk (see fe_common.h)
-template <int NP, int NFP, int M, int NB>
+template <int NP, int NFP, int M, int NB, int NF = kFmNf>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void facemass_mfma_tail_kernel(
     const double* __restrict__ J, const double* __restrict__ R, FieldPtrs P, int64_t E, int64_t nTiles, int jfe, int rlayout,
     unsigned* __restrict__ tail, int64_t t_static) {
-    facemass_mfma_body<NP, NFP, M, NB, kFmNf, false, false, false, true>(J, R, nullptr, P, E, nTiles, jfe, rlayout, blockIdx.x,
-                                                                         gridDim.x, tail, t_static);
+    facemass_mfma_body<NP, NFP, M, NB, NF, false, false, false, true>(J, R, nullptr, P, E, nTiles, jfe, rlayout, blockIdx.x,
+                                                                      gridDim.x, tail, t_static);
 }
 
 template <int NP, int NFP, int M, int NB, int NF = kFmNf, bool ALDS = false, bool W8 = false, bool kPrep = false>

@@ -565,7 +565,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                             hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
                             break;
                         }
-                        if constexpr (NP == 35) {   // b fields (the batched launches of the other orders walk statically)
+                        {   // b fields
                             static PerDeviceOnce once_tail_b;
                             snprintf(what, sizeof(what), "grad Np=%d M=%d x b, dynamic walk", NP, M);
                             if (int rc = configured(once_tail_b, fe::grad3d_mfma_tail_kernel<NP, M, 0, true>, what, G::LDS_BYTES, 256, 2)) return rc;
@@ -643,7 +643,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                             hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
                             break;
                         }
-                        if constexpr (NP == 35) {   // b fields (the batched launches of the other orders walk statically)
+                        {   // b fields
                             static PerDeviceOnce once_tail_b;
                             snprintf(what, sizeof(what), "div Np=%d M=%d x b, dynamic walk", NP, M);
                             if (int rc = configured(once_tail_b, fe::div3d_mfma_tail_kernel<NP, M, true>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU))
@@ -761,16 +761,16 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
             return FE_OK;
         }
     }
-    if constexpr (NF == fe::kFmNf && !ALDS && (NB == 3 || NB == 4)) {   // tetrahedra p = 1 .. 4
+    if constexpr (!ALDS && NB >= 3) {   // tetrahedra p = 1 .. 4 and triangles, three or more fields
         // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
         const int64_t t_static = tail_static_tiles(nTiles, blocks, G::WAVES);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
-            snprintf(what, sizeof(what), "face-mass Np=%d M=%d b=%d, dynamic walk", NP, M, NB);
-            if (int rc = configured(once_tail, fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>, what, G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
+            snprintf(what, sizeof(what), "face-mass Np=%d nf=%d M=%d b=%d, dynamic walk", NP, NF, M, NB);
+            if (int rc = configured(once_tail, fe::facemass_mfma_tail_kernel<NP, NFP, M, NB, NF>, what, G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
                 return rc;
-            hipLaunchKernelGGL((fe::facemass_mfma_tail_kernel<NP, NFP, M, NB>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s,
+            hipLaunchKernelGGL((fe::facemass_mfma_tail_kernel<NP, NFP, M, NB, NF>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s,
                                J, R, P, E, nTiles, jfe, rifj, tail, t_static);
             return FE_OK;
         }
@@ -999,7 +999,21 @@ int launch_nd2(const double* J, const double* D, const fe::FieldPtrs& P, int nb,
         return configure_kernel(fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU);
     });
     if (attr_rc != FE_OK) return attr_rc;
-    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(persistent_grid(nTiles, G::WAVES)), dim3(256),
+    const unsigned grid = persistent_grid(nTiles, G::WAVES);
+    if constexpr (MODE == 0 || MODE == 4) {   // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
+        const int64_t t_static = tail_static_tiles(nTiles, grid, G::WAVES);
+        unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+        if (tail) {
+            static PerDeviceOnce once_tail;
+            char what[64];
+            snprintf(what, sizeof(what), "triangles %s Np=%d M=%d, dynamic walk", MODE == 4 ? "grad" : "div", NP, M);
+            if (int rc = configured(once_tail, fe::nd2_mfma_tail_kernel<NP, M, MODE>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+            hipLaunchKernelGGL((fe::nd2_mfma_tail_kernel<NP, M, MODE>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT,
+                               tail, t_static);
+            return FE_OK;
+        }
+    }
+    hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 0, MODE, 2>), dim3(grid), dim3(256),
                        G::LDS_BYTES, s, J, D, nullptr, P, nb, E, nTiles, opT, jes);
     return FE_OK;
 }

@@ -806,3 +806,58 @@ def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
                         assert torch.equal(static[out_name], dynamic[out_name]), (name, E, rounds, out_name)
     finally:
         _hip.set_tail_rounds(before)
+
+
+def _two_dimensional(name, Np, Nfp):
+    J, R = f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np))
+    if name == "grad2":
+        return f.einsum("xre,rij,ej->xei", J, R, f.array("u", ("E", Np)))
+    if name == "div2":
+        return f.einsum("xre,rij,xej->ei", J, R, f.array("u", (2, "E", Np)))
+    if name == "bgrad2":
+        return f.batched_einsum("xre,rij,ej->xei", [[J, R, f.array(f"u{k}", ("E", Np))] for k in range(3)])
+    return f.batched_einsum("ef,fij,fej->ei", [[f.array("J", ("E", 3)), f.array("R", (3, Np, Nfp)), f.array(f"v{k}", (3, "E", Nfp))]
+                                               for k in range(3)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,Np,Nfp", [("grad2", 15, 5), ("div2", 15, 5), ("lift2", 15, 5), ("bgrad2", 15, 5), ("grad2", 6, 3),
+                                         ("div2", 21, 6), ("lift2", 10, 4), ("batched_grad_p3", 20, 0), ("batched_div_p3", 20, 0),
+                                         ("batched_grad_p2", 10, 0), ("batched_div_p1", 4, 0), ("face_mass_b5", 35, 15),
+                                         ("face_mass_b3_p2", 10, 6)])
+def test_dynamic_walk_of_the_other_kernels(torch_cuda, name, Np, Nfp):
+    """Round 4: the triangles' kernels (grad by components, div, lift), the batched launches of the orders p = 1 ... 3 and
+    face-mass launches of any three or more fields take their tiles by tickets too.  Same property as
+    above: the bits of the static walk, at sizes around the switch and in launches of alternating sizes one after the other."""
+    torch = torch_cuda
+    from feinsum_amd import _hip
+
+    if name.startswith("batched_grad"):
+        expr = dg.batched_grad(3, Np)
+    elif name.startswith("batched_div"):
+        expr = dg.batched_div(3, Np)
+    elif name == "face_mass_b5":
+        expr = dg.face_mass(5)
+    elif name == "face_mass_b3_p2":
+        expr = dg.face_mass(3, 10, 4, 6)
+    else:
+        expr = _two_dimensional(name, Np, Nfp)
+    assert f.match_family(expr) is not None
+    # a wave tile is 16 M elements (M = 1 ... 8 by kernel and order): sizes that give 5+ rounds of 2048 waves for every M
+    sizes = [2048 * 16 * 8 * 5, 2048 * 16 * 8 * 5 + 77, 1_500_007, 2048 * 16 * 8 * 5]
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        for E in sizes:
+            dev = _device_inputs(torch, expr, E, seed=E % 1000)
+            _hip.set_tail_rounds(-1)
+            static = {k: v.clone() for k, v in f.evaluate(expr, 0, dev, transform="mfma", wait=True).items()}
+            for rounds in (1 << 20, 3):
+                _hip.set_tail_rounds(rounds)
+                for _ in range(2):
+                    dynamic = f.evaluate(expr, 0, dev, transform="mfma", wait=True)
+                    for out_name in static:
+                        assert torch.equal(static[out_name], dynamic[out_name]), (name, E, rounds, out_name)
+            del dev, static, dynamic
+    finally:
+        _hip.set_tail_rounds(before)
+    assert _hip.tail_check()["dirty_words"] == 0

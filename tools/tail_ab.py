@@ -19,7 +19,21 @@ from feinsum_amd import _hip, measure, placement  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "grad"
 E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 rounds = [int(r) for r in (sys.argv[3] if len(sys.argv) > 3 else "-1 1 2 3 6 12").split()]
-expr = {"grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4), "grad5": lambda: dg.grad(56), "div5": lambda: dg.div(56),
+def _tri(kind, Np=15, Nfp=5):
+    J, R = f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np))
+    if kind == "grad":
+        return f.einsum("xre,rij,ej->xei", J, R, f.array("u", ("E", Np)))
+    if kind == "div":
+        return f.einsum("xre,rij,xej->ei", J, R, f.array("u", (2, "E", Np)))
+    return f.batched_einsum("ef,fij,fej->ei", [[f.array("J", ("E", 3)), f.array("R", (3, Np, Nfp)), f.array(f"v{k}", (3, "E", Nfp))]
+                                               for k in range(3)])
+
+
+expr = {"grad2": lambda: _tri("grad"), "div2": lambda: _tri("div"), "lift2": lambda: _tri("lift"),
+        "grad2p2": lambda: _tri("grad", 6, 3), "div2p5": lambda: _tri("div", 21, 6),
+        "bgrad3p3": lambda: dg.batched_grad(3, 20), "bdiv3p3": lambda: dg.batched_div(3, 20), "bgrad3p2": lambda: dg.batched_grad(3, 10),
+        "fm5": lambda: dg.face_mass(5), "fm3p3": lambda: dg.face_mass(3, 20, 4, 10),
+        "grad": dg.grad, "div": dg.div, "facemass": lambda: dg.face_mass(4), "grad5": lambda: dg.grad(56), "div5": lambda: dg.div(56),
         "facemass5": lambda: dg.face_mass(4, Np=56, Nfp=21), "bdiv3": lambda: dg.batched_div(3), "bgrad3": lambda: dg.batched_grad(3)}[what]()
 nbytes = measure._get_footprint_gbytes(expr, E) * 1e9
 flops = f.count_ops(expr, long_dim_length=E)
