@@ -692,6 +692,22 @@ def main() -> None:
                    "kernel_ms_static_walk": None if static_walk_ms is None else round(static_walk_ms, 5)}
 
     want_gather = parallel.in_group() and args.gather_fields == "on"
+    # A/B outside the timed region: the streamed operand fetched the other way (plain loads while the launch's inputs fit the
+    # Infinity Cache, non-temporal otherwise: feinsum_amd/csrc/fe_common.h, fe_set_temporal_loads_mib)
+    in_bytes = sum(int(t.numel()) * t.element_size() for t in {id(t): t for _, d in stages for t in d.values()}.values())
+    mib_setting = _hip.set_temporal_loads_mib(0)
+    floor = {"div": 80, "facemass": 64}.get(args.workload, 0) << 20       # (single div / face-mass launches: measured floors)
+    plain = floor <= in_bytes <= (mib_setting << 20) and in_bytes > 0
+    loads_report = {"threshold_mib": mib_setting, "launch_input_mib": round(in_bytes / 2**20, 1),
+                    "streamed_operand": "plain loads (the launch's inputs fit the 256 MiB Infinity Cache: a repeated launch finds them there)"
+                    if plain else "non-temporal loads"}
+    try:
+        if not args.no_protocol and plain:
+            step_batch(max(args.warmup, 10))
+            loads_report["kernel_ms_non_temporal_loads"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
+    finally:
+        _hip.set_temporal_loads_mib(mib_setting)
+
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
 
@@ -714,7 +730,7 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
-                 "walk": walk_report,
+                 "walk": walk_report, "loads": loads_report,
                  "dist_backend": info.backend if parallel.in_group() else None,
                  # the optional full-field exchange runs BEHIND this line (rank 0 reports it on stderr): whatever happens
                  # inside a 6.7 GB-per-GPU collective cannot cost the scaling record

@@ -91,10 +91,11 @@ struct DivGeom {
     // and a separate o buffer resident (86 + 29 KB for four waves at Np = 56) there is no room for
     // the fragments.
     static constexpr bool STREAM = ALDS && MODE == 0;
-    static_assert(!W8 || (ALDS && BYCOMP && M == 1), "eight-wave blocks: grad by components, A in LDS");
+    static_assert(!W8 || (ALDS && (BYCOMP || MODE == 0) && M == 1), "eight-wave blocks: grad by components or div, A in LDS");
     static_assert(MODE != 5 || (W8 && ND == 3), "grad planes by components: the eight-wave p = 5 kernel");
     struct WaveLds {
-        double u[STREAM ? 2 : NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]
+        double u[STREAM ? (W8 ? 1 : 2) : NPLANES][PLANE_D];   // u[x][e0 .. e0+TEL-1][0..Np-1]  (STREAM: plane buffers; W8: ONE, which is
+                                                              // also the output transposition buffer)
         double o[(STREAM || W8) ? 2 : SUB_D];      // output transposition buffer (one 16-element sub-tile)
         double j[NJ > 0 ? NJ * TEL : 2];   // J[x*3+r][e0 + 0..TEL-1]   (MODE 1: J[s][..] or J[..][s]; MODE 2: J[..])
     };
@@ -259,7 +260,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     if constexpr (G::STREAM) {
         // ---- plane streaming (see DivGeom): per (tile, field) unit
         //   L(p0), L(J) | L(p1) -> B += plane 0 | L(p2) -> B += plane 1 -> B += plane 2 | L(p0', J') | MFMAs | stores
-        const unsigned lds_a = lds_addr_uniform(L->u[0]), lds_b = lds_addr_uniform(L->u[1]);
+        const unsigned lds_a = lds_addr_uniform(L->u[0]), lds_b = lds_addr_uniform(L->u[W8 ? 0 : 1]);
         auto issue_plane = [&](int64_t t, int fk, int x, unsigned lds) {
             const char* up = reinterpret_cast<const char*>(field_in(P, fk)) + ((int64_t)x * E + t * G::TEL) * (NP * 8);
 #pragma unroll
@@ -280,6 +281,100 @@ __device__ __forceinline__ void div3d_mfma_body(
         static_assert(ND == 3, "three planes");
         bool first = true;
         int fk = 0;
+        if constexpr (W8) {
+            // ---- eight waves per block = two per SIMD (round 4): a wave's own VALU work and memory stalls never hide under its
+            //      own MFMAs (profiles/r04/mfma_valu_overlap.txt) -- a second wave on the SIMD is what covers them.  Beside 75 KB
+            //      of fragments there is room for ONE plane buffer per wave, so a unit is a serial chain
+            //        L(p0), L(J) | B = J p0 | L(p1) | B += J p1 | L(p2) | B += J p2 | 210 MFMAs | out through the buffer | L(p0', J')
+            //      whose three load latencies the partner wave's MFMA phase covers.
+            //      Measured (profiles/r04/p5_div_eight_waves.txt): 0.402 against 0.411-0.417 ms for four waves.  Fetching the
+            //      next unit's three planes into REGISTERS before the MFMA phase (84 more VGPRs, 252 in all) took the load
+            //      latencies off the chain and changed nothing (0.403 ms): what binds is the matrix pipe plus the f64 VALU work
+            //      of both waves (the B fragments: 126 f64 operations behind 126 LDS reads per unit), not the loads.
+            (void)lds_b;
+            if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
+            while (tile < tEnd) {
+                double* const out = field_out(P, fk);
+                const bool next_new_tile = (fk + 1 == nb);
+                const int64_t nt = next_new_tile ? tile + stride : tile;
+                const int nk = next_new_tile ? 0 : fk + 1;
+                wait_vmcnt<0>();                                  // p0 and J landed (and the previous unit's stores left)
+                double jac[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
+                double bfrag[G::KSJ][3];
+                auto add_plane = [&](int x) {
+#pragma unroll
+                    for (int jq = 0; jq < G::KSJ; ++jq) {
+                        const double v = L->u[0][tile_index<NP>(n, 4 * jq + g)];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) bfrag[jq][r] = x == 0 ? jac[r] * v : __builtin_fma(jac[x * 3 + r], v, bfrag[jq][r]);
+                    }
+#pragma unroll
+                    for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bfrag[jq][r]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the plane is in registers: its buffer may be refilled
+                };
+                add_plane(0);
+                issue_plane(tile, fk, 1, lds_a);
+                wait_vmcnt<0>();
+                add_plane(1);
+                issue_plane(tile, fk, 2, lds_a);
+                wait_vmcnt<0>();
+                add_plane(2);
+
+                v4d acc[G::BT];
+                double accs[G::NS > 0 ? G::NS : 1];
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+#pragma unroll
+                for (int jq = 0; jq < G::KSJ; ++jq)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                        for (int t = 0; t < G::BT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bfrag[jq][r], acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < G::NS; ++q)
+                            accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16], bfrag[jq][r],
+                                                                         accs[q], 0, 0, 0);
+                    }
+                double* ob = L->u[0];                             // the plane buffer as the output transposition buffer
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
+#pragma unroll
+                for (int q = 0; q < G::NS; ++q) {
+                    const int i = 16 * G::BT + 4 * q + g;
+                    if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
+                }
+                wave_lds_fence();
+                double* op = out + tile * G::TEL * NP;
+                v2d held[G::SUB_INSTR];
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    held[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc))
+                                                                                  : v2d{0.0, 0.0};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // o is in registers before the buffer is refilled
+                if (nt < tEnd) { issue_plane(nt, nk, 0, lds_a); issue_j(nt); }
+#pragma unroll
+                for (int c = 0; c < G::SUB_INSTR; ++c) {
+                    const int qc = c * 64 + lane;
+                    if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS)
+                        __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+                wave_lds_fence();
+                fk = nk;
+                tile = nt;
+            }
+            return;
+        }
         // (tickets -- fe_common.h, dynamic walk -- were measured here too: 46.9 against 48.1 TFLOP/s, profiles/r03/dynamic_walk_p5.txt)
         if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
         while (tile < tEnd) {

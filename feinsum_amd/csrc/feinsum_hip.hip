@@ -389,9 +389,28 @@ int launch_gradplanes_p5(const fe::GradFields& Q, const double* D, int nb, int64
     return FE_OK;
 }
 
-// div of tetrahedra p = 5: the A fragments in LDS and the u planes streamed through two buffers
+// div of tetrahedra p = 5: the A fragments in LDS and the u planes streamed -- eight waves per block with one plane buffer each
+// (round 4; FEINSUM_DIV_P5_WAVES=4: round 2's four waves with two buffers each, kept for the A/B)
 int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT,
                   hipStream_t s, bool* launched) {
+    static const bool four_waves = [] { const char* e = getenv("FEINSUM_DIV_P5_WAVES"); return e && atoi(e) == 4; }();
+    if (!four_waves) {
+        using G = fe::DivGeom<56, 1, 0, 3, true, true>;
+        const int64_t nTiles = E / G::TEL;
+        *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
+        if (nTiles == 0) return FE_OK;
+        static PerDeviceOnce once;
+        const int attr_rc = once.run([] {
+            return configure_kernel(fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true, true>, "div p5 (A in LDS, planes streamed, eight waves)", G::LDS_BYTES,
+                                    G::THREADS, G::BLOCKS_PER_CU);
+        });
+        if (attr_rc != FE_OK) return attr_rc;
+        const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
+        const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+        hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true, true>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr, P,
+                           nb, E, nTiles, opT, 0);
+        return FE_OK;
+    }
     using G = fe::DivGeom<56, 1, 0, 3, true>;
     const int64_t nTiles = E / G::TEL;
     *launched = nTiles > 0;   // the launch covers the elements behind the last tile too
