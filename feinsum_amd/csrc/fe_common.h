@@ -345,18 +345,28 @@ __device__ __forceinline__ void balance_priority(bool younger_half, int iteratio
     }
 }
 
-// The elements behind the last full wave tile: done by block 0 before its own tiles (while its
-// first tiles stream in), with the plain per-entry code of the generic kernels (item(e, i)
-// computes output entry i of element e).  Block 0 is among the first to finish -- the older half
-// of the grid ends several us before the younger half -- so the few us this takes are hidden; a
-// separate launch for the remainder cost ~8 us, a third of a whole launch at E = 1e5.
+// The elements behind the last full wave tile (fewer than 16 M of them): the MFMA bodies never mask or clamp, so these are
+// computed with the plain per-entry code of the generic kernels (item(e, i) = output entry i of element e), one entry per
+// thread, by as few blocks as that takes -- before their own tiles, while their first tiles stream in.  Which blocks: the ones
+// at the END OF THE OLDER HALF of the grid.  At E = 1e6 any block hides the few microseconds this takes; at E ~ 5e4 nothing
+// hides it and the launch lasts as long as its slowest block -- round 3 gave all entries to block 0 (two or three entries per
+// thread, one after the other: div at E = 45 000 took 22 us against 12 for E = 44 992, profiles/r04/temporal_loads_ab.txt),
+// whose waves are also among those with the most tiles.  The older half starts its tiles ~3 us before the younger one (it
+// wins the issue arbitration during the prologue), and within it the highest block indices are the first to have a tile
+// fewer when the tiles do not fill the last round.
 template <class F>
 __device__ __forceinline__ void remainder_items(int64_t e_begin, int64_t E, int Np, unsigned bid, unsigned nblk,
                                                 F item) {
-    (void)nblk;
-    if (bid != 0) return;
     const int64_t n = (E - e_begin) * Np;
-    for (int64_t idx = threadIdx.x; idx < n; idx += blockDim.x) item(e_begin + idx / Np, (int)(idx % Np));
+    if (n <= 0) return;
+    const unsigned per = blockDim.x;
+    const int64_t want = (n + per - 1) / per;                       // blocks at one entry per thread
+    const unsigned k = want < (int64_t)nblk ? (unsigned)want : nblk;
+    const unsigned half = (nblk + 1) / 2;
+    const unsigned first = half >= k ? half - k : 0;
+    if (bid < first || bid >= first + k) return;
+    for (int64_t idx = (int64_t)(bid - first) * per + threadIdx.x; idx < n; idx += (int64_t)k * per)
+        item(e_begin + idx / Np, (int)(idx % Np));
 }
 
 }  // namespace fe

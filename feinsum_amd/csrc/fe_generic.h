@@ -23,6 +23,7 @@ __device__ __forceinline__ void div3d_item(const double* __restrict__ J, const d
     const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
     const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
     double acc = 0.0;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j) {
         const double a = u0[j], b = u1[j], c = u2[j];
         const double ju0 = jac[0] * a + jac[3] * b + jac[6] * c;  // r = 0: sum_x J[x,0,e] u[x,e,j]
@@ -48,6 +49,7 @@ __device__ __forceinline__ void grad_nd_item(const double* __restrict__ J, const
     double t[3] = {0.0, 0.0, 0.0};
     const double* ue = u + e * Np;
     const int si = opT ? 1 : Np, sj = opT ? Np : 1;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j)
         for (int r = 0; r < nd; ++r) t[r] += D[(int64_t)r * Np * Np + (int64_t)i * si + j * sj] * ue[j];
     for (int x = 0; x < nd; ++x) {
@@ -62,6 +64,7 @@ __device__ __forceinline__ void div_nd_item(const double* __restrict__ J, const 
                                             int Np, int nd, int64_t e, int i, int opT) {
     const int si = opT ? 1 : Np, sj = opT ? Np : 1;
     double acc = 0.0;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j)
         for (int r = 0; r < nd; ++r) {
             double ju = 0.0;
@@ -84,6 +87,7 @@ __device__ __forceinline__ void divcomp3d_item(const double* __restrict__ J, con
     const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
     const double* ue = u + e * Np;
     double acc = 0.0;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j)
         acc += (d0[j * sj] * j0 + d1[j * sj] * j1 + d2[j * sj] * j2) * ue[j];
     out[e * Np + i] = acc;
@@ -100,6 +104,7 @@ __device__ __forceinline__ void divcomp_nd_item(const double* __restrict__ J, co
         const double js = jes ? J[e * nd + s] : J[(int64_t)s * E + e];
         const double* d = D + (int64_t)s * Np * Np + (int64_t)i * si;
         double t = 0.0;
+#pragma unroll 5
         for (int j = 0; j < Np; ++j) t += d[j * sj] * ue[j];
         acc += js * t;
     }
@@ -122,6 +127,7 @@ __device__ __forceinline__ void matapply_item(const double* __restrict__ J, cons
     const int sj = opT ? Np : 1;
     const double* ue = u + e * Np;
     double acc = 0.0;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j) acc += d[j * sj] * ue[j];
     out[e * Np + i] = J ? J[e] * acc : acc;
 }
@@ -147,6 +153,7 @@ __device__ __forceinline__ void facemass_item(const double* __restrict__ J, cons
         const double jf = J[e * jEs + f * jFs];
         const double* rr = R + (int64_t)f * rF + (int64_t)i * rI;
         const int64_t vo = ((int64_t)f * E + e) * Nfp;
+#pragma unroll 5
         for (int j = 0; j < Nfp; ++j) {
             const double w = rr[j * rJ] * jf;
 #pragma unroll

@@ -115,6 +115,7 @@ __device__ __forceinline__ void grad3d_item(const double* __restrict__ J, const 
     const double* d0 = D + (int64_t)0 * Np * Np + (int64_t)i * si;
     const double* d1 = D + (int64_t)1 * Np * Np + (int64_t)i * si;
     const double* d2 = D + (int64_t)2 * Np * Np + (int64_t)i * si;
+#pragma unroll 5
     for (int j = 0; j < Np; ++j) {
         const double uj = ue[j];
         t0 += d0[j * sj] * uj;
