@@ -20,23 +20,28 @@ namespace fe {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct GradF32Geom {
-    static constexpr int NP = 35, TEL = 16, RT = 7, TG = 9, KS = 9;
-    static constexpr int TILE_F = TEL * NP;             // floats: u tile / one out plane of a tile (560)
-    static constexpr int U_CHUNKS = TILE_F / 4;         // 16-byte chunks (140)
-    static constexpr int U_INSTR = (U_CHUNKS + 63) / 64;            // 3
-    static constexpr int J_ROW_CHUNKS = TEL / 4;        // 4
-    static constexpr int J_CHUNKS = 9 * J_ROW_CHUNKS;   // 36
-    static constexpr int J_INSTR = 1;
+// M = 16-element sub-tiles per wave iteration.  M = 1 (round 3): 2.2 KB spans per plane and tile, three blocks per CU.  M = 2
+// (round 4): a wave tile is 32 elements, so that a plane leaves as one 4.5 KB burst -- the float64 kernel's span -- through an
+// output buffer that holds both sub-tiles; 20 KB of LDS per wave, two blocks per CU.
+template <int M_ = 2>
+struct GradF32GeomT {
+    static constexpr int M = M_;
+    static constexpr int NP = 35, TEL = 16 * M, RT = 7, TG = 9, KS = 9;
+    static constexpr int TILE_F = TEL * NP;             // floats: u tile / one out plane of a tile (560 M)
+    static constexpr int U_CHUNKS = TILE_F / 4;         // 16-byte chunks (140 M)
+    static constexpr int U_INSTR = (U_CHUNKS + 63) / 64;            // 3 / 5
+    static constexpr int J_ROW_CHUNKS = TEL / 4;        // 4 M
+    static constexpr int J_CHUNKS = 9 * J_ROW_CHUNKS;   // 36 M
+    static constexpr int J_INSTR = (J_CHUNKS + 63) / 64;            // 1 / 2
     static constexpr int LOADS = U_INSTR + J_INSTR;
-    static constexpr int PLANE_STORES = U_INSTR;        // 16-byte chunks of one plane of a tile: 140
+    static constexpr int PLANE_STORES = U_INSTR;        // 16-byte chunks of one plane of a tile
     static constexpr int STORES = 3 * PLANE_STORES;
     struct WaveLds {
         float u[2][TILE_F];      // prefetch double buffer
-        float j[2][9 * TEL];     // J[x*3+r][e0 .. e0+15], double buffered
+        float j[2][9 * TEL];     // J[x*3+r][e0 .. e0+TEL-1], double buffered
     };
     struct WaveOut {
-        float o[2][TILE_F];      // output transposition buffers, alternating
+        float o[2][TILE_F];      // output transposition buffers (a whole plane of the tile), alternating
     };
     static constexpr int WAVES = 4;
     static constexpr int OP_F = 3 * NP * NP;            // 3675 floats
@@ -44,11 +49,12 @@ struct GradF32Geom {
     static constexpr int OUT_BYTES = (int)sizeof(WaveOut) * WAVES;
     static constexpr int OP_BYTES = (OP_F * 4 + 15) / 16 * 16;
     static constexpr int LDS_BYTES = IN_BYTES + (OUT_BYTES > OP_BYTES ? OUT_BYTES : OP_BYTES);
-    static constexpr int BLOCKS_PER_CU = 3;             // 40 KB of LDS per block of four waves; four blocks (128 VGPRs, 12 B of
-                                                        // scratch) ran 6 % slower: profiles/r03/float32_grad.txt
+    static constexpr int BLOCKS_PER_CU = M == 1 ? 3 : 2;   // M = 1: 40 KB of LDS per block of four waves; four blocks (128 VGPRs, 12 B of
+                                                           // scratch) ran 6 % slower: profiles/r03/float32_grad.txt
     static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
 };
+using GradF32Geom = GradF32GeomT<1>;
 
 __device__ __forceinline__ void grad3d_item_f32(const float* __restrict__ J, const float* __restrict__ D,
                                                 const float* __restrict__ u, float* __restrict__ out, int64_t E, int Np,
@@ -71,16 +77,17 @@ __device__ __forceinline__ void grad3d_item_f32(const float* __restrict__ J, con
                            __builtin_fmaf(J[(int64_t)(x * 3 + 1) * E + e], t1, J[(int64_t)(x * 3 + 0) * E + e] * t0));
 }
 
-__global__ __launch_bounds__(256, 3) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
-                                                                 const float* __restrict__ u, float* __restrict__ out,
-                                                                 int64_t E, int64_t nTiles, int opT) {
-    using G = GradF32Geom;
+template <int M = 1>
+__global__ __launch_bounds__(256, M == 1 ? 3 : 2) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
+                                                                             const float* __restrict__ u, float* __restrict__ out,
+                                                                             int64_t E, int64_t nTiles, int opT) {
+    using G = GradF32GeomT<M>;
     constexpr int NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    G::WaveLds* L = reinterpret_cast<G::WaveLds*>(smem) + wave;
-    G::WaveOut* LO = reinterpret_cast<G::WaveOut*>(smem + G::IN_BYTES) + wave;
+    typename G::WaveLds* L = reinterpret_cast<typename G::WaveLds*>(smem) + wave;
+    typename G::WaveOut* LO = reinterpret_cast<typename G::WaveOut*>(smem + G::IN_BYTES) + wave;
     const int n = lane & 15, g = lane >> 4;
     const unsigned bid = blockIdx.x, nblk = gridDim.x;
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
@@ -93,9 +100,13 @@ __global__ __launch_bounds__(256, 3) void grad3d_mfma_f32_kernel(const float* __
             if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) glds16_nt(ub + c * 1024, lds_u + c * 1024);
     };
     auto issue_j = [&](int64_t t, unsigned lds_j) {
-        const int row = lane / G::J_ROW_CHUNKS, col = lane - row * G::J_ROW_CHUNKS;   // chunk -> (row x*3 + r, column chunk)
-        const char* src = reinterpret_cast<const char*>(J + (int64_t)row * E + t * G::TEL) + col * 16;
-        if (lane < G::J_CHUNKS) glds16(src, lds_j);
+#pragma unroll
+        for (int c = 0; c < G::J_INSTR; ++c) {
+            const int q = c * 64 + lane;
+            const int row = q / G::J_ROW_CHUNKS, col = q - row * G::J_ROW_CHUNKS;   // chunk -> (row x*3 + r, column chunk)
+            const char* src = reinterpret_cast<const char*>(J + (int64_t)row * E + t * G::TEL) + col * 16;
+            if ((c + 1) * 64 <= G::J_CHUNKS || q < G::J_CHUNKS) glds16(src, lds_j + c * 1024);
+        }
     };
 
     // ---- the loads of this wave's first two tiles (LDS-DMA), and behind them the operator -> LDS (over the output
@@ -181,39 +192,45 @@ __global__ __launch_bounds__(256, 3) void grad3d_mfma_f32_kernel(const float* __
 
         const float* ut = L->u[buf];
         const float* jt = L->j[buf];
-        // ---- stage 1
-        float bfrag[G::KS];
+        // ---- stage 1, sub-tile by sub-tile
+        v4f acc[M][G::RT];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int j = 4 * ks + g;
-            const float b = ut[n * NP + (j < NP ? j : 0)];
-            bfrag[ks] = (j < NP) ? b : 0.f;
+        for (int m = 0; m < M; ++m) {
+            float bfrag[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const int j = 4 * ks + g;
+                const float b = ut[(16 * m + n) * NP + (j < NP ? j : 0)];
+                bfrag[ks] = (j < NP) ? b : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < G::RT; ++t) acc[m][t] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][ks], bfrag[ks], acc[m][t], 0, 0, 0);
         }
-        v4f acc[G::RT];
-#pragma unroll
-        for (int t = 0; t < G::RT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < G::RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
 
-        // ---- stage 2 + transposed store, plane by plane
+        // ---- stage 2 + transposed store, plane by plane (both sub-tiles of a plane leave together)
         const int64_t e0 = tile * G::TEL;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             float* ob = LO->o[x & 1];
-            const float j0 = jt[(x * 3 + 0) * G::TEL + n];
-            const float j1 = jt[(x * 3 + 1) * G::TEL + n];
-            const float j2 = jt[(x * 3 + 2) * G::TEL + n];
 #pragma unroll
-            for (int k = 0; k < G::TG; ++k) {
-                const int s = 3 * k;
-                const float t0 = acc[(s + 0) >> 2][(s + 0) & 3];
-                const float t1 = acc[(s + 1) >> 2][(s + 1) & 3];
-                const float t2 = acc[(s + 2) >> 2][(s + 2) & 3];
-                const float val = __builtin_fmaf(j2, t2, __builtin_fmaf(j1, t1, j0 * t0));
-                const int i = G::TG * g + k;
-                if (G::TG * 3 + k < NP || i < NP) ob[n * NP + i] = val;
+            for (int m = 0; m < M; ++m) {
+                const float j0 = jt[(x * 3 + 0) * G::TEL + 16 * m + n];
+                const float j1 = jt[(x * 3 + 1) * G::TEL + 16 * m + n];
+                const float j2 = jt[(x * 3 + 2) * G::TEL + 16 * m + n];
+#pragma unroll
+                for (int k = 0; k < G::TG; ++k) {
+                    const int s = 3 * k;
+                    const float t0 = acc[m][(s + 0) >> 2][(s + 0) & 3];
+                    const float t1 = acc[m][(s + 1) >> 2][(s + 1) & 3];
+                    const float t2 = acc[m][(s + 2) >> 2][(s + 2) & 3];
+                    const float val = __builtin_fmaf(j2, t2, __builtin_fmaf(j1, t1, j0 * t0));
+                    const int i = G::TG * g + k;
+                    if (G::TG * 3 + k < NP || i < NP) ob[(16 * m + n) * NP + i] = val;
+                }
             }
             wave_lds_fence();
             float* op = out + ((int64_t)x * E + e0) * NP;

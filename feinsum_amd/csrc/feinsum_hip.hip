@@ -2147,19 +2147,30 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
             return FE_OK;
         }
         if (aligned) {
-            using G = fe::GradF32Geom;
-            static PerDeviceOnce once;
-            if (int rc = configured(once, fe::grad3d_mfma_f32_kernel, "grad float32 Np=35", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
-            const int64_t nTiles = a->E / G::TEL;
-            int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
-            const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
-            if (blocks > cap) blocks = cap;
-            for (int k = 0; k < b; ++k)
-                hipLaunchKernelGGL(fe::grad3d_mfma_f32_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
-                                   reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
-                                   reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
-            FE_HIP_CHECK(hipGetLastError());
-            return FE_OK;
+            // two 16-element sub-tiles per wave iteration from E = 2e5 on (round 4: 4.5 KB store bursts, two blocks per CU: 68.1 ->
+            // 70.5 % of the float32 roofline at 1e6, 70.2 -> 75.5 % at 4e6; below 2e5 the three-blocks-per-CU kernel of one sub-tile
+            // is faster: 15.3 against 17.7 us at 1e5; FEINSUM_F32_M=1 / 2 forces either; profiles/r04/float32_grad_two_subtiles.txt)
+            static const int m_env = [] { const char* e = getenv("FEINSUM_F32_M"); return e ? atoi(e) : 0; }();
+            const bool m1 = m_env == 1 || (m_env != 2 && a->E < 200000);
+            auto launch = [&](auto geom, auto kernel, const char* what) -> int {
+                using G = decltype(geom);
+                static PerDeviceOnce once;
+                if (int rc = configured(once, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                const int64_t nTiles = a->E / G::TEL;
+                if (nTiles == 0) return 1;   // too few elements for a wave tile: the tiled kernel
+                int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+                const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+                if (blocks > cap) blocks = cap;
+                for (int k = 0; k < b; ++k)
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
+                                       reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
+                                       reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+                FE_HIP_CHECK(hipGetLastError());
+                return FE_OK;
+            };
+            const int rc = m1 ? launch(fe::GradF32GeomT<1>{}, fe::grad3d_mfma_f32_kernel<1>, "grad float32 Np=35 M=1")
+                              : launch(fe::GradF32GeomT<2>{}, fe::grad3d_mfma_f32_kernel<2>, "grad float32 Np=35 M=2");
+            if (rc <= 0) return rc;
         }
     }
     for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {   // groups of up to kMaxFields fields share the staged operator
