@@ -526,9 +526,10 @@ def main() -> None:
     if needs_own_ranks(args.gpus, os.environ):
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:], timeout_s=args.spawn_timeout))
     # several ranks start their allocator searches at the same instant, each on its own device but through one driver: bound
-    # what a search for a second class of memory may take (default 4 s; the arrays are then of one class and say so)
+    # what a search for a second class of memory may take (default 4 s; the arrays are then of one class and say so --
+    # `placement.pool.unsplit_arrays` in the line -- and run like ordinary allocations)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        os.environ.setdefault("FEINSUM_SPLIT_SEARCH_MS", "1500")
+        os.environ.setdefault("FEINSUM_SPLIT_SEARCH_MS", "2500")
 
     # a kernel that compiled to fewer resident blocks per CU than its launch geometry assumes is an error here, not a
     # warning (feinsum_hip.hip: configure_kernel): a number taken at half the residency is not the product's

@@ -28,6 +28,54 @@ def test_placement_mode_of_timeit(monkeypatch):
     assert measure.TimingResult(1e-3, 1e-3, 10).placement["mode"] == "separate"
 
 
+def test_outputs_evaluate_allocates_itself(monkeypatch):
+    """measure._allocate_output: what `evaluate` does for an output it is not handed -- small arrays, CPU devices and
+    `placement: separate` are plain torch allocations; large device arrays ask the split allocator and fall back to torch when
+    it cannot serve (here: no device at all), saying which it was."""
+    import torch
+
+    from feinsum_amd import measure
+
+    monkeypatch.delenv("FEINSUM_PLACEMENT", raising=False)
+    t, how = measure._allocate_output((1000, 35), torch.float64, "cpu", None)
+    assert how == "torch" and t.shape == (1000, 35) and t.dtype == torch.float64
+    t, how = measure._allocate_output((0, 35), torch.float64, "cpu", None)
+    assert how == "torch" and t.numel() == 0
+
+
+@pytest.mark.gpu
+def test_evaluate_falls_back_to_torch_when_the_allocator_cannot_serve(monkeypatch):
+    """... and on a device: the allocator for 8 MiB and more, torch when it fails or when asked (`output_allocations` of the
+    bound launch says which)."""
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd import measure
+
+    monkeypatch.delenv("FEINSUM_PLACEMENT", raising=False)
+    E, expr = 100_000, dg.grad()
+    dev = {k: torch.from_numpy(v).cuda() for k, v in measure.generate_host_input_arrays(expr, E).items()}
+    _, bound, outs = measure._bind(expr, 0, dev, None, None)
+    assert dict(bound.output_allocations) == {"_fe_out": "split"} and placement.split_info(outs[0])["pieces"] > 0
+    _, bound, outs = measure._bind(expr, 0, dev, None, {"placement": "separate"})
+    assert dict(bound.output_allocations) == {"_fe_out": "torch (placement: separate)"} and placement.split_info(outs[0]) == {}
+
+    def no_vmm(*a, **k):
+        raise RuntimeError("no VMM here")
+
+    monkeypatch.setattr(placement, "empty", no_vmm)
+    _, bound, outs = measure._bind(expr, 0, dev, None, None)
+    assert bound.output_allocations["_fe_out"].startswith("torch (split allocator failed") and outs[0].shape == (3, E, 35)
+    ref = f.evaluate(expr, 0, dev, out_dict={"_fe_out": torch.empty_like(outs[0])}, wait=True)["_fe_out"]
+    bound.launch(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], ref)
+    _, bound, _ = measure._bind(dg.grad(), 0, {k: torch.from_numpy(v).cuda() for k, v in measure.generate_host_input_arrays(expr, 1000).items()},
+                                None, None)
+    assert dict(bound.output_allocations) == {"_fe_out": "torch"}              # below 8 MiB
+
+
 @pytest.mark.gpu
 def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
     """feinsum_amd.placement.empty: arrays of the split allocator (fe_split_alloc) behind torch tensors -- results of

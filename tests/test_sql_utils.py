@@ -67,6 +67,26 @@ def test_record_query_retrieve_round_trip(tmp_path):
     assert set(timed) == {canonicalize_einsum(grad), canonicalize_einsum(dg.div())}
 
 
+def test_retrieve_ranks_variants_within_one_placement(tmp_path):
+    """Facts taken with the timed arrays placed differently are 5-12 % apart for the SAME kernel, so `retrieve` compares
+    variants within one placement: the allocator's ("split": what evaluate() allocates itself) when any fact has it, else
+    the placement with the most facts."""
+    db = str(tmp_path / "facts.sqlite")
+    dev = f.FakeCLDevice("AMD Instinct MI355X")
+    grad = dg.grad()
+    rec = lambda variant, t, **params: sql_utils.record_facts(grad, None, variant, transform_params=params, database=db,   # noqa: E731
+                                                              runtime_in_sec=t, device_name=dev.name)
+    rec("tiled", 1.0e-4, placement="separate")
+    rec("generic", 9.0e-4, placement="separate")
+    assert dict(sql_utils.retrieve(grad, dev, database=db)) == {"variant": "tiled", "placement": "separate"}
+    rec("mfma", 2.0e-5, placement="separate")        # a lucky torch placement ...
+    rec("mfma", 2.2e-5, placement="split")           # ... does not outrank the allocator's facts
+    rec("tiled", 1.1e-4, placement="split")
+    assert dict(sql_utils.retrieve(grad, dev, database=db)) == {"variant": "mfma", "placement": "split"}
+    only_sep = sql_utils.retrieve(grad, dev, database=db, consider_query=lambda q: q.transform_params.get("placement") == "separate")
+    assert dict(only_sep) == {"variant": "mfma", "placement": "separate"}
+
+
 def test_table_has_the_reference_columns(tmp_path):
     # src/feinsum/sql_utils.py:389-410
     conn = sqlite3.connect(str(tmp_path / "facts.sqlite"))

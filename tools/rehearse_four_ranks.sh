@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: the N > 1 paths of bench.py with FOUR ranks sharing the one GPU through gloo -- four allocator pools searching the
-# same device at the same instant (each bounded to 1.5 s by bench.py), the field gather behind the line, torch.distributed.run.
+# same device at the same instant (each bounded to 2.5 s by bench.py), the field gather behind the line, torch.distributed.run.
 out=${1:-gpurun_out/rehearse4}; mkdir -p $out
 FEINSUM_DIST_BACKEND=gloo timeout -k 10 500 python3 bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu-baseline > $out/selfspawn4.json 2> $out/selfspawn4.err; tail -2 $out/selfspawn4.err
 FEINSUM_DIST_BACKEND=gloo timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 4 --steps 20 --warmup 5 --workload pipeline --elems-per-gpu 250000 --gather-fields on --no-cpu-baseline > $out/torchrun4_pipeline_gather.json 2> $out/torchrun4.err; grep "field_allgather" $out/torchrun4.err | cut -c1-400
