@@ -10,6 +10,20 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+#ifdef MFMA_F32   // the same probe with v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles too)
+#define ACC_T v16f
+#define ACC_ZERO {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define MFMA_ASM "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+#define AB_T float
+#define MFMA_NAME "v_mfma_f32_32x32x2_f32"
+#else
+#define ACC_T v4d
+#define ACC_ZERO {0, 0, 0, 0}
+#define MFMA_ASM "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
+#define AB_T double
+#define MFMA_NAME "v_mfma_f64_16x16x4_f64"
+#endif
 
 __device__ unsigned long long result[16];
 
@@ -21,8 +35,9 @@ __global__ __launch_bounds__(512) void probe(double* sink, int iters, int second
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = i * 1e-3;
     __syncthreads();
     const bool mfma_wave = __builtin_amdgcn_readfirstlane(wave) < 4;   // waves 4..7 (when launched): side work only (wave-uniform: scalar branches)
-    v4d acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0;
+    ACC_T acc0 = ACC_ZERO, acc1 = acc0, acc2 = acc0;
     double a = 1.0 + lane * 1e-3, b = 2.0 - lane * 1e-3;
+    AB_T ma = (AB_T)a, mb = (AB_T)b;
     double f[16];
     float g[16];
     unsigned h[16];
@@ -44,11 +59,11 @@ __global__ __launch_bounds__(512) void probe(double* sink, int iters, int second
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (mfma_wave) {
         for (int it = 0; it < iters; ++it) {   // three accumulators in turn: an MFMA never waits for its predecessor's result
-            if (MFMA) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc0) : "v"(ma), "v"(mb));
             side();
-            if (MFMA) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc1) : "v"(ma), "v"(mb));
             side();
-            if (MFMA) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc2) : "v"(ma), "v"(mb));
             side();
         }
     } else if (second_wave_mode) {
@@ -98,7 +113,7 @@ int run2(const char* what, double* sink) {
 int main() {
     double* sink;
     CK(hipMalloc(&sink, 64));
-    printf("# one wave per SIMD: per v_mfma_f64_16x16x4_f64 (three independent accumulators in turn): the MFMA + N side instructions behind it (shader cycles, s_memtime)\n");
+    printf("# " MFMA_NAME "\n# one wave per SIMD: per MFMA (three independent accumulators in turn): the MFMA + N side instructions behind it (shader cycles, s_memtime)\n");
     run<0, 0>("nothing", sink);
     run<2, 0>("v_fma_f64 (independent)", sink); run<4, 0>("v_fma_f64 (independent)", sink); run<8, 0>("v_fma_f64 (independent)", sink); run<16, 0>("v_fma_f64 (independent)", sink);
     run<4, 4>("v_fma_f64 (one chain)", sink); run<8, 4>("v_fma_f64 (one chain)", sink);
