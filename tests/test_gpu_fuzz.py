@@ -18,6 +18,15 @@ def test_random_cases_all_variants():
     assert fuzz_gpu.run_einsum(120, seed=7) == 0
 
 
+def test_random_dynamic_walk_cases():
+    """Random large launches (all orders, batched, triangles, fused operators) on random streams, grid sizes and load modes:
+    bitwise the static walk with non-temporal loads on the full grid; every ticket counter zero afterwards."""
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import fuzz_gpu
+
+    assert fuzz_gpu.run_dynamic_walk(24, seed=11) == 0
+
+
 def test_empty_batch_of_planes():
     # E = 0: empty tensors have no addresses; the planes launch must not mistake them for unwanted planes
     import torch

@@ -146,44 +146,73 @@ def run_einsum(n_cases: int, seed: int) -> int:
 
 def run_dynamic_walk(n_cases: int, seed: int) -> int:
     """Launches large enough for the dynamic walk (five or more rounds of tiles: fe_common.h) -- single launches of all
-    tetrahedral orders and fused operators at random element counts: tickets against the static walk, bitwise, and the
-    ticket launch a second time (its counters must have been left zeroed)."""
+    tetrahedral orders, batched launches, triangles, fused operators at random element counts: tickets against the static
+    walk, bitwise, and the ticket launch a second time (its counters must have been left zeroed).  Round 4: on a random stream
+    (the default one or a fresh one: the counters belong to the stream), with a random grid size (fe_set_cu_limit: grids of
+    fewer than 128 blocks must walk statically) and a random load mode (fe_set_temporal_loads_mib)."""
     from feinsum_amd import _hip
 
     rng.seed(seed)
     failures = 0
     before = _hip.set_tail_rounds(1 << 20)
+    before_cus, before_mib = _hip.set_cu_limit(0), _hip.set_temporal_loads_mib(248)
     try:
         for case in range(n_cases):
             Np, Nfp = rng.choice(ORDERS3[:5])
             E = rng.randrange(170_000 if Np >= 20 else 900_000, 700_000 if Np >= 20 else 1_300_000)
-            kind = rng.choice(["grad", "div", "fm3", "fm4", "operator"])
+            kind = rng.choice(["grad", "div", "fm3", "fm4", "fm5", "bgrad", "bdiv", "grad2", "div2", "lift2", "operator"])
             if kind == "operator":
                 exprs = [dg.div(Np), dg.grad(Np), dg.face_mass(rng.choice([2, 3, 4]), Np=Np, Nfp=Nfp)]
+            elif kind.endswith("2"):
+                Np, Nfp = rng.choice(ORDERS2)
+                E = rng.randrange(1_400_000, 1_800_000)
+                J, R = f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np))
+                b = rng.choice([1, 2, 3])
+                exprs = [{"grad2": lambda: f.batched_einsum("xre,rij,ej->xei", [[J, R, f.array(f"u{k}", ("E", Np))] for k in range(b)]),
+                          "div2": lambda: f.batched_einsum("xre,rij,xej->ei", [[J, R, f.array(f"u{k}", (2, "E", Np))] for k in range(b)]),
+                          "lift2": lambda: f.batched_einsum("ef,fij,fej->ei", [[f.array("J", ("E", 3)), f.array("R", (3, Np, Nfp)),
+                                                                               f.array(f"v{k}", (3, "E", Nfp))] for k in range(3)])}[kind]()]
             else:
+                b = rng.choice([2, 3])
                 exprs = [{"grad": lambda: dg.grad(Np), "div": lambda: dg.div(Np), "fm3": lambda: dg.face_mass(3, Np=Np, Nfp=Nfp),
-                          "fm4": lambda: dg.face_mass(4, Np=Np, Nfp=Nfp)}[kind]()]
+                          "fm4": lambda: dg.face_mass(4, Np=Np, Nfp=Nfp), "fm5": lambda: dg.face_mass(5, Np=Np, Nfp=Nfp),
+                          "bgrad": lambda: dg.batched_grad(b, Np), "bdiv": lambda: dg.batched_div(b, Np)}[kind]()]
             gen = torch.Generator(device="cuda").manual_seed(case)
             devs = [{a: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in e.arg_to_shape[a]), dtype=torch.float64,
                                    device="cuda", generator=gen) for a in sorted(e.all_args)} for e in exprs]
             if len(exprs) == 3:
                 devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+            q = f.DeviceQueue(0, stream=torch.cuda.Stream()) if rng.random() < 0.5 else f.DeviceQueue(0)
+            torch.cuda.synchronize()
 
             def evaluate():
                 if len(exprs) == 1:
-                    return [f.evaluate(exprs[0], 0, devs[0], wait=True)]
-                return f.evaluate_operator(list(zip(exprs, devs)), 0, wait=True)
+                    return [f.evaluate(exprs[0], q, devs[0], wait=True)]
+                return f.evaluate_operator(list(zip(exprs, devs)), q, wait=True)
             _hip.set_tail_rounds(-1)
+            _hip.set_cu_limit(0)
+            _hip.set_temporal_loads_mib(0)
             static = [{k: v.clone() for k, v in o.items()} for o in evaluate()]
-            _hip.set_tail_rounds(rng.choice([1 << 20, 1 << 20, 1, 4]))
+            rounds, cus, mib = rng.choice([1 << 20, 1 << 20, 1, 4]), rng.choice([0, 0, 0, 32, 64, 100, 160]), rng.choice([0, 248, 1 << 20])
+            _hip.set_tail_rounds(rounds)
+            _hip.set_cu_limit(cus)
+            _hip.set_temporal_loads_mib(mib)
             for rep in range(2):
                 for o_static, o in zip(static, evaluate()):
                     for k in o_static:
                         if not torch.equal(o_static[k], o[k]):
                             failures += 1
-                            print(f"FAIL dynamic walk case {case}: {kind} Np={Np} E={E} output {k} (launch {rep})", flush=True)
+                            print(f"FAIL dynamic walk case {case}: {kind} Np={Np} E={E} rounds={rounds} cus={cus} loads<={mib}MiB output {k} (launch {rep})",
+                                  flush=True)
+            del static, devs
+        dirty = _hip.tail_check()["dirty_words"]
+        if dirty:
+            failures += 1
+            print(f"FAIL: {dirty} ticket-counter words left non-zero", flush=True)
     finally:
         _hip.set_tail_rounds(before)
+        _hip.set_cu_limit(before_cus)
+        _hip.set_temporal_loads_mib(before_mib)
     print(f"{n_cases} dynamic-walk cases, failures {failures}")
     return failures
 
