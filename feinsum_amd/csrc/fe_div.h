@@ -221,7 +221,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);
         if (tload) {   // (fe_common.h, kOpLoadsTemporal: one scalar branch for the whole unit)
 #pragma unroll
-            for (int x = 0; x < G::NPLANES; ++x) {
+            for (int x = 0; x < ((kDbg & 32) ? 1 : G::NPLANES); ++x) {   // (kDbg & 32, experiments build: one plane only -- timing, wrong results)
                 const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
                 for (int c = 0; c < G::P_INSTR; ++c)

@@ -629,6 +629,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 2>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
         }
         return FE_OK;
     });
@@ -643,6 +644,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 2: FE_DIV_CASE(2); break;
         case 3: FE_DIV_CASE(3); break;
         case 8: FE_DIV_CASE(8); break;
+        case 32: FE_DIV_CASE(32); break;   // one u plane loaded instead of three (timing only)
 #endif
         default:
             if (prep) {
