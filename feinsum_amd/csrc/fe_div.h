@@ -843,6 +843,23 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
         }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
+        if constexpr ((kDbg & 64) != 0 && MODE == 0 && ND == 3 && M == 1) {
+            // experiment (kDbg & 64): touch the tile AFTER next -- one dword per 128-byte line of its three planes and nine J rows --
+            // so that its LDS-DMA loads, which can only go out one MFMA phase ahead of their use, find the lines in the L2
+            const int64_t pt = nt + stride;
+            if (pt < tEnd) {
+                double sink = 0.0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int line = c * 64 + lane;                 // 3 x 35 plane lines, then 9 J lines
+                    const char* a = nullptr;
+                    if (line < 105) a = reinterpret_cast<const char*>(field_in(P, 0)) + ((int64_t)(line / 35) * E + pt * G::TEL) * (NP * 8) + (line % 35) * 128;
+                    else if (line < 114) a = reinterpret_cast<const char*>(J) + ((int64_t)(line - 105) * E + pt * G::TEL) * 8;
+                    if (a) { float v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(a) : "memory"); sink += v; }
+                }
+                asm volatile("" :: "v"(sink));
+            }
+        }
 
         if (MODE == 4) {   // grad by components: separate accumulators per r, J contraction in the epilogue
 #pragma unroll

@@ -630,6 +630,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 3>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
         }
         return FE_OK;
     });
@@ -645,6 +646,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 3: FE_DIV_CASE(3); break;
         case 8: FE_DIV_CASE(8); break;
         case 32: FE_DIV_CASE(32); break;   // one u plane loaded instead of three (timing only)
+        case 64: FE_DIV_CASE(64); break;   // the tile after next touched line by line (L2 prefetch)
 #endif
         default:
             if (prep) {
@@ -1455,7 +1457,7 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
     }
     int64_t e_done = 0;
     if (path == kPathMfma) {
-        const int dbg = variant >= 1000 ? (variant - 1000) & 15 : 0;   // experiment builds only
+        const int dbg = variant >= 1000 ? (variant - 1000) & 127 : 0;   // experiment builds only
         int rc = FE_OK;
         const int opf = opT | (split_walk ? fe::kDivWalkSplit : 0);
         switch (Np) {   // wave tile = 16 M elements
