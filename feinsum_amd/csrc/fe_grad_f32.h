@@ -15,6 +15,7 @@
 // launcher sends other sizes to the tiled kernel); the elements behind the last full tile are done by block 0.
 #pragma once
 #include "fe_common.h"
+#include "fe_grad.h"   // grad_row_tiles
 
 namespace fe {
 
@@ -23,10 +24,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // M = 16-element sub-tiles per wave iteration.  M = 1 (round 3): 2.2 KB spans per plane and tile, three blocks per CU.  M = 2
 // (round 4): a wave tile is 32 elements, so that a plane leaves as one 4.5 KB burst -- the float64 kernel's span -- through an
 // output buffer that holds both sub-tiles; 20 KB of LDS per wave, two blocks per CU.
-template <int M_ = 2>
+// NP (round 4): the tetrahedral orders p = 1 ... 4 (Np = 4, 10, 20, 35) as in fe_grad.h -- RT row tiles such that the four
+// lane groups hold TG = 4 RT / 3 whole r-triples with 4 TG >= Np; the lower orders take more sub-tiles per wave iteration
+// (a wave tile of a few KB).
+template <int M_ = 2, int NP_ = 35>
 struct GradF32GeomT {
     static constexpr int M = M_;
-    static constexpr int NP = 35, TEL = 16 * M, RT = 7, TG = 9, KS = 9;
+    static constexpr int NP = NP_, TEL = 16 * M, RT = grad_row_tiles(NP_), TG = (4 * RT) / 3, KS = (NP_ + 3) / 4;
     static constexpr int TILE_F = TEL * NP;             // floats: u tile / one out plane of a tile (560 M)
     static constexpr int U_CHUNKS = TILE_F / 4;         // 16-byte chunks (140 M)
     static constexpr int U_INSTR = (U_CHUNKS + 63) / 64;            // 3 / 5
@@ -49,7 +53,7 @@ struct GradF32GeomT {
     static constexpr int OUT_BYTES = (int)sizeof(WaveOut) * WAVES;
     static constexpr int OP_BYTES = (OP_F * 4 + 15) / 16 * 16;
     static constexpr int LDS_BYTES = IN_BYTES + (OUT_BYTES > OP_BYTES ? OUT_BYTES : OP_BYTES);
-    static constexpr int BLOCKS_PER_CU = M == 1 ? 3 : 2;   // M = 1: 40 KB of LDS per block of four waves; four blocks (128 VGPRs, 12 B of
+    static constexpr int BLOCKS_PER_CU = (M == 1 && NP == 35) ? 3 : 2;   // M = 1: 40 KB of LDS per block of four waves; four blocks (128 VGPRs, 12 B of
                                                            // scratch) ran 6 % slower: profiles/r03/float32_grad.txt
     static_assert(BLOCKS_PER_CU * LDS_BYTES <= 160 * 1024, "blocks per CU");
     static_assert(LOADS + STORES <= 60, "counted vmcnt must fit the 6-bit field");
@@ -77,11 +81,11 @@ __device__ __forceinline__ void grad3d_item_f32(const float* __restrict__ J, con
                            __builtin_fmaf(J[(int64_t)(x * 3 + 1) * E + e], t1, J[(int64_t)(x * 3 + 0) * E + e] * t0));
 }
 
-template <int M = 1>
-__global__ __launch_bounds__(256, M == 1 ? 3 : 2) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
+template <int M = 1, int NP_ = 35>
+__global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
                                                                              const float* __restrict__ u, float* __restrict__ out,
                                                                              int64_t E, int64_t nTiles, int opT) {
-    using G = GradF32GeomT<M>;
+    using G = GradF32GeomT<M, NP_>;
     constexpr int NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;

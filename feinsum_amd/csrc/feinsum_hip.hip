@@ -2085,7 +2085,8 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
     // grad of tetrahedra p = 4 on the matrix cores (fe_grad_f32.h): 16-byte aligned operands, E a multiple of 4 (so that
     // every row of J and every output plane starts on a 16-byte boundary) and at least one full tile; else the tiled kernel
     // div and face-mass likewise (fe_div_f32.h, fe_facemass_f32.h)
-    const bool mfma_shape = (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35) || (family == FE_FAMILY_DIV && ndim == 3 && a->Np == 35) ||
+    const bool grad_lower = family == FE_FAMILY_GRAD && ndim == 3 && (a->Np == 20 || a->Np == 10 || a->Np == 4);   // p = 1 ... 3 (round 4)
+    const bool mfma_shape = grad_lower || (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35) || (family == FE_FAMILY_DIV && ndim == 3 && a->Np == 35) ||
                             (family == FE_FAMILY_FACEMASS && a->Np == 35 && nf == 4 && Nfp == 15);
     if (mfma_shape && a->variant != FE_VARIANT_TILED && a->E % 4 == 0 && a->E >= 16) {
         bool aligned = ((reinterpret_cast<uintptr_t>(a->J) | reinterpret_cast<uintptr_t>(a->D)) & 15u) == 0;
@@ -2172,8 +2173,11 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
                 FE_HIP_CHECK(hipGetLastError());
                 return FE_OK;
             };
-            const int rc = m1 ? launch(fe::GradF32GeomT<1>{}, fe::grad3d_mfma_f32_kernel<1>, "grad float32 Np=35 M=1")
-                              : launch(fe::GradF32GeomT<2>{}, fe::grad3d_mfma_f32_kernel<2>, "grad float32 Np=35 M=2");
+            const int rc = a->Np == 20 ? launch(fe::GradF32GeomT<3, 20>{}, fe::grad3d_mfma_f32_kernel<3, 20>, "grad float32 Np=20 M=3")
+                           : a->Np == 10 ? launch(fe::GradF32GeomT<5, 10>{}, fe::grad3d_mfma_f32_kernel<5, 10>, "grad float32 Np=10 M=5")
+                           : a->Np == 4 ? launch(fe::GradF32GeomT<8, 4>{}, fe::grad3d_mfma_f32_kernel<8, 4>, "grad float32 Np=4 M=8")
+                           : m1 ? launch(fe::GradF32GeomT<1>{}, fe::grad3d_mfma_f32_kernel<1>, "grad float32 Np=35 M=1")
+                                : launch(fe::GradF32GeomT<2>{}, fe::grad3d_mfma_f32_kernel<2>, "grad float32 Np=35 M=2");
             if (rc <= 0) return rc;
         }
     }
