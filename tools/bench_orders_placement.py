@@ -1,8 +1,8 @@
 """MFMA kernels of all tetrahedral orders: every array from torch ("separate") against outputs from the split allocator
-("split", timeit's default; pass "tuned" as a second argument to add round 2's arena scan), and the split placement once more
+("split", timeit's default; round 2's arena scan, "tuned", was removed in round 4), and the split placement once more
 with the static walk (fe_set_tail_rounds(-1)).
 
-    python tools/bench_orders_placement.py [E] [tuned]
+    python tools/bench_orders_placement.py [E]
 """
 import sys
 
@@ -20,7 +20,7 @@ for Np, Nfp in ((4, 3), (10, 6), (20, 10), (35, 15), (56, 21)):
         gops = f.count_ops(expr, long_dim_length=E) * 1e-9
         roof = f.get_roofline_flop_rate(expr, "AMD Instinct MI355X", E)[np.dtype("float64")]
         row = []
-        modes = ["separate", "split"] + (["tuned"] if "tuned" in sys.argv[2:] else [])
+        modes = ["separate", "split"]
         for what, tr in ((m, {"variant": "mfma", "placement": m}) for m in modes):
             r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
             row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")

@@ -1,4 +1,4 @@
-"""p = 5 (Np = 56) MFMA kernels: one torch allocation per array against the tuned placement (feinsum_amd.placement).
+"""p = 5 (Np = 56) MFMA kernels: one torch allocation per array against outputs from the split allocator (feinsum_amd.placement; round 2 compared against its arena scan, removed in round 4).
 
     python tools/bench_p5_placement.py [E]
 """
@@ -18,7 +18,7 @@ for name, expr in cases:
     gops = f.count_ops(expr, long_dim_length=E) * 1e-9
     roof = f.get_roofline_flop_rate(expr, "AMD Instinct MI355X", E)[np.dtype("float64")]
     row = []
-    for what, tr in (("separate", {"variant": "mfma", "placement": "separate"}), ("tuned", {"variant": "mfma", "placement": "tuned"}),
+    for what, tr in (("separate", {"variant": "mfma", "placement": "separate"}), ("split", {"variant": "mfma", "placement": "split"}),
                      ("separate", {"variant": "mfma", "placement": "separate"})):
         r = f.timeit_details(expr, cq=0, transform=tr, long_dim_length=E, min_secs=0.5)
         row.append(f"{what} {r.seconds_device * 1e3:7.4f} ms {gops / r.seconds_device:7.0f} GF/s ({gops / r.seconds_device / roof * 100:4.1f} %)")
