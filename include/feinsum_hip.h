@@ -16,8 +16,11 @@
  * Conventions (all launchers):
  *   - all pointers are DEVICE pointers to C-contiguous float64 arrays;
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
- *     NULL = the default stream); nothing is allocated, no ownership moves:
- *     the caller keeps every buffer alive until it synchronises the stream;
+ *     NULL = the default stream); no ownership moves: the caller keeps every
+ *     buffer alive until it synchronises the stream; the launchers allocate
+ *     nothing but the ticket-counter chunks of the dynamic walk (8.9 MB per
+ *     sixteen streams, on demand, never inside a stream capture: see
+ *     fe_stream_retired below);
  *   - inputs are read-only, outputs are fully overwritten (the reference's
  *     kernels assign, they do not accumulate: codegen/loopy.py:289-305);
  *   - E is the "long" element axis (feinsum SizeParam, einsum.py:26-41);
@@ -25,8 +28,11 @@
  *   - return 0 on success, a negative FE_E* code otherwise; the message is
  *     available from fe_last_error() (thread-local).
  *   - thread-safety: re-entrant; distinct streams may be driven from distinct
- *     host threads.  No global mutable state besides an init-once attribute
- *     cache and the record of prepared-operator buffers (fe_prepare_operator).
+ *     host threads, captured graphs replayed beside eager launches.  Mutable
+ *     state: an init-once attribute cache, the record of prepared-operator
+ *     buffers (fe_prepare_operator), and the ticket counters -- which belong to
+ *     the launch's stream (or graph node), so that launches that can overlap
+ *     never share any.
  *
  * `variant` selects the kernel implementation (the build's replacement for the
  * reference's transform archive lookup, sql_utils.py:247-294):
