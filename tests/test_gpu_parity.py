@@ -723,6 +723,8 @@ F32_CASES = {
     "batched_grad_b3": lambda: dg.batched_grad(3), "batched_div_b2": lambda: dg.batched_div(2),
     "mass_apply_b4": lambda: dg.mass_apply(4), "operator_apply": lambda: dg.operator_apply(),
     "grad_p3": lambda: dg.grad(20), "div_p2": lambda: dg.div(10), "grad_p5": lambda: dg.grad(56),
+    # round 4: the float32 MFMA grad kernel is templated on Np (p = 1 ... 3 ran on the tiled kernel before)
+    "grad_p1": lambda: dg.grad(4), "grad_p2": lambda: dg.grad(10), "grad_t_p3": lambda: dg.grad_t(20), "batched_grad_b3_p2": lambda: dg.batched_grad(3, 10),
     "face_mass_p5": lambda: dg.face_mass(4, Np=56, Nfp=21), "face_mass_b9": lambda: dg.face_mass(9),
     "div_t": lambda: dg.div_t(), "face_mass_b1": lambda: dg.face_mass(1), "face_mass_b2": lambda: dg.face_mass(2),
     "face_mass_b3": lambda: dg.face_mass(3), "face_mass_jfi_fe": lambda: dg.face_mass_jfi_fe(4), "face_mass_fji": lambda: dg.face_mass_fji(2),
@@ -731,7 +733,7 @@ F32_CASES = {
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(F32_CASES))
-@pytest.mark.parametrize("E", [1, 37, 1000, 10007, 70004])
+@pytest.mark.parametrize("E", [1, 37, 132, 1000, 10007, 70004])
 def test_float32_families(torch_cuda, name, E):
     """All-float32 DG einsums (the reference validates float32 at 1e-6: src/feinsum/measure.py:178-192) run on the
     matrix cores (grad / div / face-mass at p = 4 with E a multiple of 4: fe_grad_f32.h, fe_div_f32.h, fe_facemass_f32.h;
