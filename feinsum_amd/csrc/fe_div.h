@@ -126,8 +126,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
     const GradFields* __restrict__ Q = nullptr, unsigned* __restrict__ tail = nullptr, int64_t t_static = 0) {
     static_assert(!kPrep || (!ALDS && MODE == 0 && ND == 3), "prepared operators: plain div of tetrahedra");
-    static_assert(!kDyn || ((MODE == 0 || MODE == 4) && !ALDS && !W8 && !kPrep) || (MODE == 4 && ND == 3 && W8),
-                  "dynamic walk: div (tetrahedra, triangles), grad by components (triangles), or the eight-wave grad by components (p = 5)");
+    static_assert(!kDyn || ((MODE == 0 || MODE == 4) && !ALDS && !W8 && !kPrep) || ((MODE == 4 || MODE == 0) && ND == 3 && W8),
+                  "dynamic walk: div (tetrahedra, triangles), grad by components (triangles), or the eight-wave kernels (p = 5)");
     // op_flags: bit 0 = operator stored transposed ([r][j][i]); bit 1 (kDivWalkSplit, plain register-fragment path
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
@@ -293,12 +293,27 @@ __device__ __forceinline__ void div3d_mfma_body(
             //      of both waves (the B fragments: 126 f64 operations behind 126 LDS reads per unit), not the loads.
             (void)lds_b;
             if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
+            // dynamic walk (fe_common.h; one field): the ticket for the next tile is asked for at the top of a tile -- behind the
+            // wait for its first plane -- and read behind the wait for its second plane (every wait here is vmcnt(0): the ticket,
+            // older than the second plane's loads, is back with them); the next tile's loads go out at the end of the tile
+            const bool dyn8 = kDyn && tail != nullptr && t_static < nTiles && nb == 1;   // grid-uniform
+            const int pool8 = (bid >> 3) & (kTailPools - 1);
+            unsigned* const counter8 = tail_pool_counters(tail, pool8);
+            unsigned* const done8 = tail_pool_reports(counter8);
+            bool reported8 = false;
             while (tile < tEnd) {
                 double* const out = field_out(P, fk);
                 const bool next_new_tile = (fk + 1 == nb);
-                const int64_t nt = next_new_tile ? tile + stride : tile;
+                int64_t nt = next_new_tile ? tile + stride : tile;
                 const int nk = next_new_tile ? 0 : fk + 1;
                 wait_vmcnt<0>();                                  // p0 and J landed (and the previous unit's stores left)
+                bool asked8 = false;
+                if constexpr (kDyn) {
+                    if (dyn8 && !(tile < t_static && tile + stride < t_static)) {   // the next tile is not static
+                        tail_request<0>(counter8);
+                        asked8 = true;
+                    }
+                }
                 double jac[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
@@ -319,6 +334,16 @@ __device__ __forceinline__ void div3d_mfma_body(
                 add_plane(0);
                 issue_plane(tile, fk, 1, lds_a);
                 wait_vmcnt<0>();
+                if constexpr (kDyn) {
+                    if (asked8) {   // (nothing may be outstanding: the wait above was for everything)
+                        const int64_t x = tail_ticket_tile(tail_wait<0, 0>(), t_static, pool8, tEnd);
+                        nt = x >= 0 ? x : tEnd;
+                        if (x < 0) {   // this wave's pool is empty: stop asking, report
+                            tail_request<1>(done8);
+                            reported8 = true;
+                        }
+                    }
+                }
                 add_plane(1);
                 issue_plane(tile, fk, 2, lds_a);
                 wait_vmcnt<0>();
@@ -373,9 +398,19 @@ __device__ __forceinline__ void div3d_mfma_body(
                 fk = nk;
                 tile = nt;
             }
+            if constexpr (kDyn) {
+                if (reported8) {   // the last wave of a pool to report leaves the pool's counters zeroed
+                    const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool8));
+                    const unsigned before = tail_wait<0, 1>();
+                    if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                        __hip_atomic_store(counter8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(done8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
             return;
         }
-        // (tickets -- fe_common.h, dynamic walk -- were measured here too: 46.9 against 48.1 TFLOP/s, profiles/r03/dynamic_walk_p5.txt)
+        // (tickets -- fe_common.h, dynamic walk -- were measured in the four-wave loop below too: 46.9 against 48.1 TFLOP/s, profiles/r03/dynamic_walk_p5.txt)
         if (tile < tEnd) { issue_plane(tile, 0, 0, lds_a); issue_j(tile); }
         while (tile < tEnd) {
             double* const out = field_out(P, fk);
@@ -1015,6 +1050,15 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void nd2_mfma_tail_kern
     unsigned* __restrict__ tail, int64_t t_static) {
     div3d_mfma_body<NP, M, 0, MODE, 2, false, false, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr,
                                                                   tail, t_static);
+}
+
+// div in eight-wave blocks (p = 5: A in LDS, planes streamed) with a dynamic walk
+template <int NP>
+__global__ __launch_bounds__(512, 1) FE_TAIL_KERNEL_ATTR void div_w8_tail_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
+    unsigned* __restrict__ tail, int64_t t_static) {
+    div3d_mfma_body<NP, 1, 0, 0, 3, true, true, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x, nullptr, tail,
+                                                             t_static);
 }
 
 // grad by components in eight-wave blocks (p = 5) with a dynamic walk (nb is a run-time argument although the launcher passes

@@ -407,6 +407,19 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
         if (attr_rc != FE_OK) return attr_rc;
         const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
         const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+        if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
+            const int64_t t_static = tail_static_tiles(nTiles, grid, G::WAVES);
+            unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+            if (tail) {
+                static PerDeviceOnce once_tail;
+                if (int rc = configured(once_tail, fe::div_w8_tail_kernel<56>, "div p5 (A in LDS, planes streamed, eight waves), dynamic walk",
+                                        G::LDS_BYTES, G::THREADS, G::BLOCKS_PER_CU))
+                    return rc;
+                hipLaunchKernelGGL((fe::div_w8_tail_kernel<56>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail,
+                                   t_static);
+                return FE_OK;
+            }
+        }
         hipLaunchKernelGGL((fe::div3d_mfma_kernel<56, 1, 0, 0, 3, true, true>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, J, D, nullptr, P,
                            nb, E, nTiles, opT, 0);
         return FE_OK;

@@ -826,7 +826,7 @@ def _two_dimensional(name, Np, Nfp):
 @pytest.mark.parametrize("name,Np,Nfp", [("grad2", 15, 5), ("div2", 15, 5), ("lift2", 15, 5), ("bgrad2", 15, 5), ("grad2", 6, 3),
                                          ("div2", 21, 6), ("lift2", 10, 4), ("batched_grad_p3", 20, 0), ("batched_div_p3", 20, 0),
                                          ("batched_grad_p2", 10, 0), ("batched_div_p1", 4, 0), ("face_mass_b5", 35, 15),
-                                         ("face_mass_b3_p2", 10, 6)])
+                                         ("face_mass_b3_p2", 10, 6), ("div_p5", 56, 0), ("grad_p5", 56, 0)])
 def test_dynamic_walk_of_the_other_kernels(torch_cuda, name, Np, Nfp):
     """Round 4: the triangles' kernels (grad by components, div, lift), the batched launches of the orders p = 1 ... 3 and
     face-mass launches of any three or more fields take their tiles by tickets too.  Same property as
@@ -838,6 +838,10 @@ def test_dynamic_walk_of_the_other_kernels(torch_cuda, name, Np, Nfp):
         expr = dg.batched_grad(3, Np)
     elif name.startswith("batched_div"):
         expr = dg.batched_div(3, Np)
+    elif name == "div_p5":
+        expr = dg.div(56)           # eight waves per block, planes streamed (round 4: with tickets)
+    elif name == "grad_p5":
+        expr = dg.grad(56)
     elif name == "face_mass_b5":
         expr = dg.face_mass(5)
     elif name == "face_mass_b3_p2":
