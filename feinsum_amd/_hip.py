@@ -94,6 +94,14 @@ def load_library() -> C.CDLL:
         raise HipLibraryError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (hipcc --offload-arch=gfx950) or point FEINSUM_HIP_LIB at it")
+    # torch's wheel carries its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7) and asks for it by FILE name:
+    # loaded after this library -- which resolves libamdhip64.so.7 to /opt/rocm/lib -- it becomes a SECOND runtime in the process,
+    # and launches here then fail with "no ROCm-capable device is detected" while torch owns the device.  Loaded first, its soname
+    # satisfies this library too: one runtime.  (A process without torch -- the C ABI's other callers -- has only one anyway.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(str(path))
     except OSError as exc:

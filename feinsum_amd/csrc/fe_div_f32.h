@@ -72,7 +72,9 @@ __device__ __forceinline__ void div3d_item_f32(const float* __restrict__ J, cons
 // 4 g + n / 4 of lane (g, n) is (k-slice g, element group n / 4), so the B fragment of the 16x16x4 instruction is the B operand
 // as it is, lane (g, n) supplies A = D[r][32 + n % 4][4 jq + g] and receives in register v the k-slice-g part of
 // out[e0 + n][32 + v]; the four parts are added across the lane groups at the end of the tile.
-template <int RING, bool SMALL>
+// kDbg (experiment build, $FEINSUM_F32_DBG): the tile work with parts removed -- 1 no MFMAs, 2 no stores, 4 no tile loads, 8 no
+// fragment arithmetic (profiles/r04/float32_div_decomposition.txt)
+template <int RING, bool SMALL, int kDbg = 0>
 __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
                                                                                 const float* __restrict__ u, float* __restrict__ out,
                                                                                 int64_t E, int64_t nTiles, int opT) {
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(
     const unsigned lds_s0 = lds_addr_uniform(&L->s[0]);
 
     auto issue_loads = [&](int64_t t, int slot) {
+        if (kDbg & 4) return;
         const unsigned lds_u = lds_s0 + slot * (unsigned)sizeof(typename G::Slot), lds_j = lds_u + 3 * G::PLANE_F * 4;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
-                bfrag[jq][r] = __builtin_fmaf(jac[6 + r], ux[2], __builtin_fmaf(jac[3 + r], ux[1], jac[r] * ux[0]));
+                bfrag[jq][r] = (kDbg & 8) ? ux[r] : __builtin_fmaf(jac[6 + r], ux[2], __builtin_fmaf(jac[3 + r], ux[1], jac[r] * ux[0]));
         }
         // the u / J tiles are now in registers: hand the buffers back to the DMA engine
 #pragma unroll
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int t = 0; t < G::RT; ++t) {
+                    if (kDbg & 1) { acc[t][(jq + r) & 3] += afrag[t][jq * 3 + r] + bfrag[jq][r]; continue; }
                     if (SMALL && t == 2) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
                     else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][jq * 3 + r], bfrag[jq][r], acc[t], 0, 0, 0);
                 }
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(
             const int q = c * 64 + lane;
             if ((c + 1) * 64 <= G::P_CHUNKS || q < G::P_CHUNKS) {
                 const v4f val = *reinterpret_cast<const v4f*>(ob + 4 * q);
-                __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(op + 4 * q));
+                if (kDbg & 2) { if (val[0] == 1.2345e-30f) op[4 * q] = val[1]; }   // keep the value live
+                else __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(op + 4 * q));
             }
         }
         wave_lds_fence();

@@ -81,11 +81,15 @@ __device__ __forceinline__ void grad3d_item_f32(const float* __restrict__ J, con
                            __builtin_fmaf(J[(int64_t)(x * 3 + 1) * E + e], t1, J[(int64_t)(x * 3 + 0) * E + e] * t0));
 }
 
-template <int M = 1, int NP_ = 35>
-__global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
-                                                                             const float* __restrict__ u, float* __restrict__ out,
-                                                                             int64_t E, int64_t nTiles, int opT) {
+// kDyn: behind two static rounds the tiles come by tickets (fe_common.h: dynamic walk), as in fe_grad.h
+template <int M, int NP_, bool kDyn>
+__device__ __forceinline__ void grad3d_mfma_f32_body(const float* __restrict__ J, const float* __restrict__ D,
+                                                     const float* __restrict__ u, float* __restrict__ out, int64_t E,
+                                                     int64_t nTiles, int op_flags, unsigned* __restrict__ tail = nullptr,
+                                                     int64_t t_static = 0) {
     using G = GradF32GeomT<M, NP_>;
+    const int opT = op_flags & 1;
+    const bool tload = (op_flags & kOpLoadsTemporal) != 0;   // the launch's inputs fit the Infinity Cache (fe_common.h)
     constexpr int NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -101,7 +105,10 @@ __global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfm
         const char* ub = reinterpret_cast<const char*>(u) + t * (G::TILE_F * 4) + lane * 16;
 #pragma unroll
         for (int c = 0; c < G::U_INSTR; ++c)
-            if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) glds16_nt(ub + c * 1024, lds_u + c * 1024);
+            if ((c + 1) * 64 <= G::U_CHUNKS || c * 64 + lane < G::U_CHUNKS) {
+                if (tload) glds16(ub + c * 1024, lds_u + c * 1024);
+                else glds16_nt(ub + c * 1024, lds_u + c * 1024);
+            }
     };
     auto issue_j = [&](int64_t t, unsigned lds_j) {
 #pragma unroll
@@ -117,10 +124,11 @@ __global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfm
     //      buffers, which nobody needs before the first tile's stage 2): all its loads are issued before the first LDS
     //      write, so that their latencies overlap each other and the tile loads
     bool pre = false;
+    const int64_t tPre = (kDyn && tail) ? t_static : tEnd;   // the prologue prefetches a second tile only if it is a static one
     if (tile < tEnd) {
         issue_u(tile, lds_addr_uniform(L->u[0]));
         issue_j(tile, lds_addr_uniform(L->j[0]));
-        if (tile + stride < tEnd) {
+        if (tile + stride < tPre) {
             issue_u(tile + stride, lds_addr_uniform(L->u[1]));
             issue_j(tile + stride, lds_addr_uniform(L->j[1]));
             pre = true;
@@ -172,30 +180,8 @@ __global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfm
         for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) grad3d_item_f32(J, D, u, out, E, NP, e_begin + idx / NP, (int)(idx % NP), opT);
     }
 
-    int buf = 0;
-    bool first = true;
-    const bool younger_half = bid >= (nblk + 1) / 2;
-    int iteration = 0;
-    while (tile < tEnd) {
-        balance_priority(younger_half, iteration++);
-        // vector-memory ops in issue order: L(tile) S(previous tile) L(next tile) | wait L(tile)
-        const int64_t nt = tile + stride;
-        if (nt < tEnd) {
-            if (!pre) {
-                issue_u(nt, lds_addr_uniform(L->u[buf ^ 1]));
-                issue_j(nt, lds_addr_uniform(L->j[buf ^ 1]));
-            }
-            if (first) wait_vmcnt<G::LOADS>();
-            else wait_vmcnt<G::LOADS + G::STORES>();
-        } else {
-            if (first) wait_vmcnt<0>();
-            else wait_vmcnt<G::STORES>();
-        }
-        first = false;
-        pre = false;
-
-        const float* ut = L->u[buf];
-        const float* jt = L->j[buf];
+    // one tile: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
+    auto compute_tile = [&](int64_t tile_, const float* ut, const float* jt) {
         // ---- stage 1, sub-tile by sub-tile
         v4f acc[M][G::RT];
 #pragma unroll
@@ -216,7 +202,7 @@ __global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfm
         }
 
         // ---- stage 2 + transposed store, plane by plane (both sub-tiles of a plane leave together)
-        const int64_t e0 = tile * G::TEL;
+        const int64_t e0 = tile_ * G::TEL;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             float* ob = LO->o[x & 1];
@@ -248,9 +234,120 @@ __global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfm
             }
             wave_lds_fence();
         }
+    };
+
+    const bool younger_half = bid >= (nblk + 1) / 2;
+    if constexpr (kDyn) {
+        if (tail) {
+            // ---- walk with a dynamic tail: static tiles first + k stride below t_static, then tickets.  Vector-memory ops of
+            //      an iteration in issue order: [ticket for the tile after next] L(next) S(cur); every wave has a static first
+            //      tile (t_static >= number of waves).  The bookkeeping is fe_grad.h's.
+            constexpr int NL = G::LOADS, NS = G::STORES;
+            const int pool = (bid >> 3) & (kTailPools - 1);
+            unsigned* const counter = tail_pool_counters(tail, pool);
+            unsigned* const done = tail_pool_reports(counter);
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 +
+                                         (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
+            const unsigned pool_waves = pool_blocks * G::WAVES;
+            auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
+            int64_t cur = tile < tEnd ? tile : -1, nxt = cur >= 0 ? static_next(cur) : -1;   // nxt >= 0: loaded by the prologue (pre)
+            bool pending = false, reported = false, prev_pre = false, first = true;
+            if (cur >= 0 && nxt < 0) {   // one static round: the prologue's ticket, behind L(cur)
+                tail_request<0>(counter);
+                pending = true;
+            }
+            int buf = 0, iteration = 0;
+            while (cur >= 0) {
+                balance_priority(younger_half, iteration++);
+                bool extra = false;   // one more vector-memory op (ticket or report) issued in this iteration
+                if (pending) {   // the next tile comes from a ticket: younger than it are L(cur) and S(previous)
+                    const unsigned t = first ? tail_wait<0, 0>() : prev_pre ? tail_wait<NS, 0>() : tail_wait<NL + NS, 0>();
+                    nxt = tail_ticket_tile(t, t_static, pool, tEnd);
+                    pending = false;
+                    if (nxt < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done);
+                        reported = true;
+                        extra = true;
+                    }
+                }
+                if (nxt >= 0) {
+                    if (static_next(nxt) < 0) {   // the tile after next is not static
+                        tail_request<0>(counter);
+                        pending = true;
+                        extra = true;
+                    }
+                    if (!pre) {
+                        issue_u(nxt, lds_addr_uniform(L->u[buf ^ 1]));
+                        issue_j(nxt, lds_addr_uniform(L->j[buf ^ 1]));
+                    }
+                }
+                // wait L(cur): younger are S(previous), the ticket / report, L(next)
+                if (nxt >= 0) {
+                    if (first) { if (extra) wait_vmcnt<NL + 1>(); else wait_vmcnt<NL>(); }
+                    else { if (extra) wait_vmcnt<NS + NL + 1>(); else wait_vmcnt<NS + NL>(); }
+                } else {
+                    if (first) { if (extra) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+                    else { if (extra) wait_vmcnt<NS + 1>(); else wait_vmcnt<NS>(); }
+                }
+                compute_tile(cur, L->u[buf], L->j[buf]);
+                first = false;
+                prev_pre = pre;
+                pre = false;
+                cur = nxt;
+                buf ^= 1;
+                if (cur >= 0 && !pending) nxt = static_next(cur);
+            }
+            // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch
+            if (reported) {
+                const unsigned before = tail_wait<NS, 1>();
+                if (before + 1 == pool_waves && lane == 0) {
+                    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+    }
+
+    int buf = 0;
+    bool first = true;
+    int iteration = 0;
+    while (tile < tEnd) {
+        balance_priority(younger_half, iteration++);
+        // vector-memory ops in issue order: L(tile) S(previous tile) L(next tile) | wait L(tile)
+        const int64_t nt = tile + stride;
+        if (nt < tEnd) {
+            if (!pre) {
+                issue_u(nt, lds_addr_uniform(L->u[buf ^ 1]));
+                issue_j(nt, lds_addr_uniform(L->j[buf ^ 1]));
+            }
+            if (first) wait_vmcnt<G::LOADS>();
+            else wait_vmcnt<G::LOADS + G::STORES>();
+        } else {
+            if (first) wait_vmcnt<0>();
+            else wait_vmcnt<G::STORES>();
+        }
+        first = false;
+        pre = false;
+        compute_tile(tile, L->u[buf], L->j[buf]);
         tile = nt;
         buf ^= 1;
     }
+}
+
+template <int M = 1, int NP_ = 35>
+__global__ __launch_bounds__(256, (M == 1 && NP_ == 35) ? 3 : 2) void grad3d_mfma_f32_kernel(const float* __restrict__ J, const float* __restrict__ D,
+                                                                             const float* __restrict__ u, float* __restrict__ out,
+                                                                             int64_t E, int64_t nTiles, int op_flags) {
+    grad3d_mfma_f32_body<M, NP_, false>(J, D, u, out, E, nTiles, op_flags);
+}
+
+// the same with a dynamic tail (two blocks per CU: the ticket registers v254 / v255 make the descriptor allocate 256 VGPRs)
+template <int M, int NP_ = 35>
+__global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void grad3d_mfma_f32_tail_kernel(
+    const float* __restrict__ J, const float* __restrict__ D, const float* __restrict__ u, float* __restrict__ out, int64_t E,
+    int64_t nTiles, int op_flags, unsigned* __restrict__ tail, int64_t t_static) {
+    grad3d_mfma_f32_body<M, NP_, true>(J, D, u, out, E, nTiles, op_flags, tail, t_static);
 }
 
 }  // namespace fe

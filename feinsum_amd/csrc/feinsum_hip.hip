@@ -11,6 +11,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -2130,6 +2131,15 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
             static PerDeviceOnce once2;
 #ifdef FE_EXPERIMENTS
             static PerDeviceOnce once1, once3;
+            static const int f32dbg = [] { const char* e = getenv("FEINSUM_F32_DBG"); return e ? atoi(e) : 0; }();   // parts of the tile work removed
+            static PerDeviceOnce onced[16];
+#define FE_F32DBG_CASE(D) case D: return go(fe::DivF32Geom<2>{}, fe::div3d_mfma_f32_kernel<2, true, D>, "div float32 experiment", onced[D]);
+            switch (f32dbg) {
+                FE_F32DBG_CASE(1) FE_F32DBG_CASE(2) FE_F32DBG_CASE(3) FE_F32DBG_CASE(4) FE_F32DBG_CASE(5) FE_F32DBG_CASE(6) FE_F32DBG_CASE(7)
+                FE_F32DBG_CASE(8) FE_F32DBG_CASE(9) FE_F32DBG_CASE(12) FE_F32DBG_CASE(15)
+                default: break;
+            }
+#undef FE_F32DBG_CASE
             if (ring == 1) return go(fe::DivF32Geom<1>{}, fe::div3d_mfma_f32_kernel<1, false>, "div float32 Np=35 one buffer", once1);
             if (!small) return go(fe::DivF32Geom<2>{}, fe::div3d_mfma_f32_kernel<2, false>, "div float32 Np=35 three row tiles", once3);
 #endif
@@ -2170,27 +2180,47 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
             // is faster: 15.3 against 17.7 us at 1e5; FEINSUM_F32_M=1 / 2 forces either; profiles/r04/float32_grad_two_subtiles.txt)
             static const int m_env = [] { const char* e = getenv("FEINSUM_F32_M"); return e ? atoi(e) : 0; }();
             const bool m1 = m_env == 1 || (m_env != 2 && a->E < 200000);
-            auto launch = [&](auto geom, auto kernel, const char* what) -> int {
+            // `tail_kernel`: the same kernel with a dynamic tail (behind two static rounds the tiles come by tickets; from five rounds
+            // on, as for float64) or nullptr; every launch of the loop runs on `s`, so they use the stream's counters in turn
+            auto launch = [&](auto geom, auto kernel, auto tail_kernel, const char* what) -> int {
                 using G = decltype(geom);
-                static PerDeviceOnce once;
+                static PerDeviceOnce once, once_tail;
                 if (int rc = configured(once, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
                 const int64_t nTiles = a->E / G::TEL;
                 if (nTiles == 0) return 1;   // too few elements for a wave tile: the tiled kernel
                 int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
                 const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
                 if (blocks > cap) blocks = cap;
-                for (int k = 0; k < b; ++k)
+                const int flags = opT | temporal_flag((9 + (int64_t)a->Np) * a->E * 4);
+                int64_t t_static = nTiles;
+                if constexpr (!std::is_same_v<decltype(tail_kernel), std::nullptr_t>) {
+                    t_static = tail_static_tiles(nTiles, blocks, G::WAVES);
+                    if (t_static < nTiles)
+                        if (int rc = configured(once_tail, tail_kernel, what, G::LDS_BYTES, 256, 2)) return rc;
+                }
+                for (int k = 0; k < b; ++k) {
+                    if constexpr (!std::is_same_v<decltype(tail_kernel), std::nullptr_t>) {
+                        unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
+                        if (tail) {
+                            hipLaunchKernelGGL(tail_kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
+                                               reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
+                                               reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, flags,
+                                               tail, t_static);
+                            continue;
+                        }
+                    }
                     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s,
                                        reinterpret_cast<const float*>(a->J), reinterpret_cast<const float*>(a->D),
-                                       reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+                                       reinterpret_cast<const float*>(vin[k]), reinterpret_cast<float*>(vout[k]), a->E, nTiles, flags);
+                }
                 FE_HIP_CHECK(hipGetLastError());
                 return FE_OK;
             };
-            const int rc = a->Np == 20 ? launch(fe::GradF32GeomT<3, 20>{}, fe::grad3d_mfma_f32_kernel<3, 20>, "grad float32 Np=20 M=3")
-                           : a->Np == 10 ? launch(fe::GradF32GeomT<5, 10>{}, fe::grad3d_mfma_f32_kernel<5, 10>, "grad float32 Np=10 M=5")
-                           : a->Np == 4 ? launch(fe::GradF32GeomT<8, 4>{}, fe::grad3d_mfma_f32_kernel<8, 4>, "grad float32 Np=4 M=8")
-                           : m1 ? launch(fe::GradF32GeomT<1>{}, fe::grad3d_mfma_f32_kernel<1>, "grad float32 Np=35 M=1")
-                                : launch(fe::GradF32GeomT<2>{}, fe::grad3d_mfma_f32_kernel<2>, "grad float32 Np=35 M=2");
+            const int rc = a->Np == 20 ? launch(fe::GradF32GeomT<3, 20>{}, fe::grad3d_mfma_f32_kernel<3, 20>, fe::grad3d_mfma_f32_tail_kernel<3, 20>, "grad float32 Np=20 M=3")
+                           : a->Np == 10 ? launch(fe::GradF32GeomT<5, 10>{}, fe::grad3d_mfma_f32_kernel<5, 10>, fe::grad3d_mfma_f32_tail_kernel<5, 10>, "grad float32 Np=10 M=5")
+                           : a->Np == 4 ? launch(fe::GradF32GeomT<8, 4>{}, fe::grad3d_mfma_f32_kernel<8, 4>, fe::grad3d_mfma_f32_tail_kernel<8, 4>, "grad float32 Np=4 M=8")
+                           : m1 ? launch(fe::GradF32GeomT<1>{}, fe::grad3d_mfma_f32_kernel<1>, nullptr, "grad float32 Np=35 M=1")
+                                : launch(fe::GradF32GeomT<2>{}, fe::grad3d_mfma_f32_kernel<2>, fe::grad3d_mfma_f32_tail_kernel<2>, "grad float32 Np=35 M=2");
             if (rc <= 0) return rc;
         }
     }

@@ -102,3 +102,18 @@ def test_product_package_does_not_import_the_oracle():
     for py in (ROOT / "feinsum_amd").rglob("*.py"):
         src = py.read_text()
         assert "import oracle" not in src and "from oracle" not in src, py
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """torch's wheel brings its own libamdhip64.so and asks for it by file name; this library asks for libamdhip64.so.7.  Loaded in
+    the wrong order the process held TWO HIP runtimes and every launch here failed with "no ROCm-capable device is detected"
+    (seen with a tool that loaded the library before anything imported torch).  load_library() imports torch first."""
+    import subprocess
+    import sys
+
+    code = ("from feinsum_amd import _hip\n_hip.load_library()\nimport torch\n"
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parents[1]),
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout

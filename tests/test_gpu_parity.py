@@ -810,6 +810,42 @@ def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
         _hip.set_tail_rounds(before)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["grad", "grad_t", "grad_p3", "grad_p2", "grad_p1", "batched_grad_b3", "div", "face_mass"])
+def test_float32_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
+    """The float32 matrix-core kernels take their tiles by tickets too (round 4: fe_grad_f32.h; div and face-mass keep the
+    static walk until they have one and must simply stay unaffected by the switch): bitwise the static walk's results at sizes
+    of five and more rounds for every wave tile (16 M elements, M = 2 ... 8), with elements behind the last tile, in launches of
+    alternating sizes, and with plain or non-temporal loads of the streamed operand."""
+    torch = torch_cuda
+    from feinsum_amd import _hip
+    from feinsum_amd.measure import generate_host_input_arrays
+
+    expr = _f32(F32_CASES[name]())
+    sizes = [2048 * 16 * 8 * 5, 2048 * 16 * 8 * 5 + 76, 1_500_008, 400_000, 2048 * 16 * 8 * 5]
+    before = _hip.set_tail_rounds(1 << 20)
+    before_mib = _hip.set_temporal_loads_mib(248)
+    try:
+        for E in sizes:
+            host = generate_host_input_arrays(expr, E, np_seed=E % 1000)
+            dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+            _hip.set_tail_rounds(-1)
+            _hip.set_temporal_loads_mib(0)
+            static = {k: v.clone() for k, v in f.evaluate(expr, 0, dev, wait=True).items()}
+            for rounds, mib in ((1 << 20, 248), (3, 248), (1 << 20, 0), (1 << 20, 1 << 20)):
+                _hip.set_tail_rounds(rounds)
+                _hip.set_temporal_loads_mib(mib)
+                for _ in range(2):
+                    dynamic = f.evaluate(expr, 0, dev, wait=True)
+                    for out_name in static:
+                        assert torch.equal(static[out_name], dynamic[out_name]), (name, E, rounds, mib, out_name)
+            del dev, static, dynamic, host
+    finally:
+        _hip.set_tail_rounds(before)
+        _hip.set_temporal_loads_mib(before_mib)
+    assert _hip.tail_check()["dirty_words"] == 0
+
+
 def _two_dimensional(name, Np, Nfp):
     J, R = f.array("J", (2, 2, "E")), f.array("R", (2, Np, Np))
     if name == "grad2":
