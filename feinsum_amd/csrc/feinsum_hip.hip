@@ -555,7 +555,12 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
         case 2: FE_GRAD_CASE(2); break;
+        case 3: FE_GRAD_CASE(3); break;     // data movement in: loads only
         case 4: FE_GRAD_CASE(4); break;     // temporal stores
+        case 8: FE_GRAD_CASE(8); break;     // no loads
+        case 9: FE_GRAD_CASE(9); break;     // stores + stage 2
+        case 10: FE_GRAD_CASE(10); break;   // arithmetic and LDS only
+        case 11: FE_GRAD_CASE(11); break;   // stage 2 and LDS only
         case 16: FE_GRAD_CASE(16); break;   // temporal loads
         case 20: FE_GRAD_CASE(20); break;   // both
         case 32:
