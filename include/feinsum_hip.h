@@ -370,10 +370,12 @@ typedef struct fe_argpack {
  * src/feinsum/measure.py:178-192, src/feinsum/data/device_info.py:5-26).  One entry point for the families
  * FE_FAMILY_GRAD / DIV / DIVCOMP / MATAPPLY / FACEMASS: every pointer of `args` is read as float (the struct's
  * `double` types are nominal here), layouts, `ndim` and `layout_flags` as for the float64 entry points; `prepared` is
- * ignored.  grad, div and face-mass of tetrahedra p = 4 (Np = 35, ndim 3; face-mass: nf = 4, Nfp = 15, any b, every layout)
- * run on v_mfma_f32_16x16x4_f32 (fe_grad_f32.h, fe_div_f32.h, fe_facemass_f32.h) when their operands are 16-byte aligned
- * and E is a multiple of 4 (`variant` FE_VARIANT_TILED forces the tiled kernel); everything else runs on the LDS-tiled VALU
- * kernel in float (fe_tiled.h), any shape whose operator fits in LDS (FE_EUNSUPPORTED otherwise). */
+ * ignored.  grad of tetrahedra p = 1 ... 4 (Np = 4, 10, 20, 35) and div and face-mass at p = 4 (Np = 35, ndim 3; face-mass:
+ * nf = 4, Nfp = 15, any b, every layout) run on v_mfma_f32_16x16x4_f32 (fe_grad_f32.h, fe_div_f32.h, fe_facemass_f32.h) when
+ * their operands are 16-byte aligned and E is a multiple of 4 (`variant` FE_VARIANT_TILED forces the tiled kernel); grad walks
+ * dynamically and hints its loads like the float64 kernels (fe_set_tail_rounds, fe_set_temporal_loads_mib below); everything
+ * else runs on the LDS-tiled VALU kernel in float (fe_tiled.h), any shape whose operator fits in LDS (FE_EUNSUPPORTED
+ * otherwise). */
 int fe_launch_f32(int32_t family, const fe_argpack* args, void* stream);
 
 /* Dynamic walk of the persistent kernels (feinsum_amd/csrc/fe_common.h): behind two statically walked rounds the tiles are
