@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
     "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
-    "fe_set_cu_limit", "fe_stream_retired", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib",
+    "fe_set_cu_limit", "fe_stream_retired", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -173,6 +173,8 @@ def load_library() -> C.CDLL:
     lib.fe_set_tail_rounds.argtypes = [C.c_int32]
     lib.fe_set_temporal_loads_mib.restype = C.c_int
     lib.fe_set_temporal_loads_mib.argtypes = [C.c_int32]
+    lib.fe_set_write_through_mib.restype = C.c_int
+    lib.fe_set_write_through_mib.argtypes = [C.c_int32]
     lib.fe_set_cu_limit.restype = C.c_int
     lib.fe_set_cu_limit.argtypes = [C.c_int32]
     lib.fe_stream_retired.restype = C.c_int
@@ -443,6 +445,12 @@ def tail_check(repair: bool = False) -> dict:
 def tail_plant(stream: int, value: int) -> None:
     """Test hook (fe_tail_plant): leave a stale ticket in the counter group of *stream*."""
     check(load_library().fe_tail_plant(stream, int(value)))
+
+
+def set_write_through_mib(mib: int) -> int:
+    """grad launches that write at most *mib* MiB store write-through instead of non-temporally (fe_set_write_through_mib;
+    0 = never); returns the previous setting.  A tuning knob."""
+    return int(load_library().fe_set_write_through_mib(int(mib)))
 
 
 def set_temporal_loads_mib(mib: int) -> int:

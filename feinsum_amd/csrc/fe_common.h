@@ -96,6 +96,41 @@ __device__ __forceinline__ void glds4(const void* g, unsigned lds_base) {
 // +21 % at 5e5).  The launcher sets kOpLoadsTemporal in a body's flag word when the launch reads at most kTemporalInputBytes.
 constexpr int kOpLoadsTemporal = 16;
 constexpr long long kTemporalInputBytes = 248ll << 20;
+// Output stores are non-temporal (every byte written once; plain stores cost 9 - 21 %) -- except in launches that write little
+// (kOpStoresWriteThrough, set by the launcher when the outputs are at most kWriteThroughOutputBytes): those store write-through
+// (sc0 sc1), so that no dirty line is left in the L2s when the last wave ends and the launch's end does not wait for the write-back.
+// Measured on grad (profiles/r04/store_policies_small_sizes.txt): E = 1e5 24.0 -> 23.3 us, 2e5 41.1 -> 40.6; at 5e5 write-through
+// without nt costs 16 % and with nt it is level -- the write-back at the end is a fixed cost that only short launches see.
+constexpr int kOpStoresWriteThrough = 32;
+constexpr long long kWriteThroughOutputBytes = 128ll << 20;
+// One 16-byte write-through store per lane, in the addressing form the compiler gives its own stores (wave-uniform base in
+// SGPRs + one 32-bit lane offset + immediate): with a 64-bit VGPR address per store the same instruction cost 3 - 12 %.
+// (a macro: the immediate must be a constant where the statement stands -- inside an unrolled loop it is one after unrolling)
+#define FE_STORE16_WRITE_THROUGH(base_uniform, lane_offset, val, imm)                                                     \
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1" ::"v"(lane_offset), "v"(val), "s"(base_uniform), "n"(imm))
+// (no memory clobber: the statement reads registers only, and nothing else touches the output)
+// The chunks of one [rows][NP] output tile (CHUNKS of 16 bytes, INSTR wave-instructions), already in registers, to `op`
+// (wave-uniform): non-temporal, or write-through for the short launches above.
+template <int INSTR, int CHUNKS>
+__device__ __forceinline__ void store_tile_held(double* op, int lane, const v2d (&held)[INSTR], bool write_through) {
+    if (write_through) {
+        // (the base is wave-uniform by construction; where the compiler cannot prove it, this puts it into SGPRs anyway)
+        const unsigned long long a = reinterpret_cast<unsigned long long>(op);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);          // (the builtin returns a signed int:
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));    //  widen only after the cast)
+        op = reinterpret_cast<double*>((unsigned long long)lo | ((unsigned long long)hi << 32));
+#pragma unroll
+        for (int c = 0; c < INSTR; ++c)
+            if ((c + 1) * 64 <= CHUNKS || c * 64 + lane < CHUNKS)
+                FE_STORE16_WRITE_THROUGH(op, (unsigned)(lane * 16 + (c >> 2) * 4096), held[c], (c & 3) * 1024);
+    } else {
+#pragma unroll
+        for (int c = 0; c < INSTR; ++c) {
+            const int qc = c * 64 + lane;
+            if ((c + 1) * 64 <= CHUNKS || qc < CHUNKS) __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
+        }
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

@@ -215,6 +215,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     static_assert(!kDyn || (kPlain && !kPrep), "dynamic walk: plain launches of one field");
     const int opT = op_flags & 1;                                  // operator stored transposed
     const bool tload = (op_flags & kOpLoadsTemporal) != 0;         // the u tiles by plain loads (fe_common.h)
+    const bool wthrough = !kDyn && kPlain && (op_flags & kOpStoresWriteThrough) != 0;   // short launches (static walk): fe_common.h
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -382,6 +383,19 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
                 wave_lds_fence();
                 double* op = out_x[x] + (e0 + 16 * m) * NP;
+                if constexpr (!kDyn && kPlain && kDbg == 0) {
+                    if (wthrough) {   // all values out of LDS first, then the stores back to back (as the compiler orders its own)
+                        v2d vals[G::SUB_INSTR];
+#pragma unroll
+                        for (int c = 0; c < G::SUB_INSTR; ++c) {
+                            const int q = c * 64 + lane;
+                            vals[c] = ((c + 1) * 64 <= G::SUB_CHUNKS || q < G::SUB_CHUNKS) ? *reinterpret_cast<const v2d*>(ob + 2 * q) : v2d{0.0, 0.0};
+                        }
+                        store_tile_held<G::SUB_INSTR, G::SUB_CHUNKS>(op, lane, vals, true);
+                        wave_lds_fence();
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int q = c * 64 + lane;

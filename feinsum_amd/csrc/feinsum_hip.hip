@@ -293,6 +293,16 @@ int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0) {
 }
 constexpr int64_t kTemporalFloorDiv = 80ll << 20, kTemporalFloorFaceMass = 64ll << 20;
 
+// kOpStoresWriteThrough (fe_common.h) for a launch that writes `output_bytes` ($FEINSUM_WRITE_THROUGH_MIB /
+// fe_set_write_through_mib; 0 = never)
+std::atomic<long long> g_write_through_output_bytes{[] {
+    const char* e = getenv("FEINSUM_WRITE_THROUGH_MIB");
+    return e ? (long long)atoll(e) << 20 : fe::kWriteThroughOutputBytes;
+}()};
+int write_through_flag(int64_t output_bytes) {
+    return output_bytes <= g_write_through_output_bytes.load(std::memory_order_relaxed) ? fe::kOpStoresWriteThrough : 0;
+}
+
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
 #ifndef FE_GRID_MODE
@@ -614,6 +624,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                     }
                 }
             }
+            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (static walk, one field: a short launch)
             FE_GRAD_CASE(0);
             break;
     }
@@ -2006,6 +2017,10 @@ int fe_set_tail_rounds(int32_t rounds) {
 
 int fe_set_temporal_loads_mib(int32_t mib) {
     return (int)(g_temporal_input_bytes.exchange(mib < 0 ? 0 : (long long)mib << 20) >> 20);
+}
+
+int fe_set_write_through_mib(int32_t mib) {
+    return (int)(g_write_through_output_bytes.exchange(mib < 0 ? 0 : (long long)mib << 20) >> 20);
 }
 
 int fe_set_cu_limit(int32_t cus) {

@@ -415,6 +415,11 @@ int fe_tail_plant(void* stream, uint32_t value);
  * on it. */
 int fe_set_temporal_loads_mib(int32_t mib);
 
+/* Output stores are non-temporal -- except in grad launches (p = 1..4, one field, static walk) that write at most `mib` MiB
+ * (default 128, also FEINSUM_WRITE_THROUGH_MIB; 0 = never): those store write-through (sc0 sc1), which leaves no dirty lines for
+ * the end of the launch to write back (E = 1e5: 24.0 -> 23.3 us).  Returns the previous setting.  Results do not depend on it. */
+int fe_set_write_through_mib(int32_t mib);
+
 /* Size the persistent grids as if the device had `cus` compute units (0 = what the device reports; also
  * FEINSUM_CU_LIMIT).  MI355X partitions report 32 (CPX) or 64 (QPX) CUs: grids of fewer than 128 blocks walk statically
  * (a ticket pool is drained by the blocks b with (b / 8) % 16 == pool).  Returns the previous limit.  Results do not

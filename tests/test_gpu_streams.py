@@ -237,3 +237,35 @@ def test_plain_and_non_temporal_loads_give_the_same_bits(cases, name):
                 assert torch.equal(t, static[name][n])
     finally:
         assert _hip.set_temporal_loads_mib(before) == 248
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["grad", "grad_p3", "grad_p2", "grad_p1", "div", "div_p3", "face_mass", "face_mass_b2", "face_mass_p2", "grad_2d"])
+def test_write_through_and_non_temporal_stores_give_the_same_bits(cases, name):
+    """Short grad launches (static walk, outputs of at most fe_set_write_through_mib MiB) store write-through instead of
+    non-temporally (feinsum_amd/csrc/fe_common.h): a cache policy, not arithmetic -- the same bits either way, at sizes with
+    one tile per wave, several, a partial last round and elements behind the last tile; every byte of the outputs is written
+    (NaN-filled first).  The other families never take the flag and must be unaffected by the setting."""
+    torch, *_ = cases
+    expr = {"grad": lambda: dg.grad(), "grad_p3": lambda: dg.grad(20), "grad_p2": lambda: dg.grad(10), "grad_p1": lambda: dg.grad(4),
+            "div": lambda: dg.div(), "div_p3": lambda: dg.div(20), "face_mass": lambda: dg.face_mass(4), "face_mass_b2": lambda: dg.face_mass(2),
+            "face_mass_p2": lambda: dg.face_mass(4, 10, 4, 6),
+            "grad_2d": lambda: f.einsum("xre,rij,ej->xei", f.array("J", (2, 2, "E")), f.array("R", (2, 15, 15)), f.array("u", ("E", 15)))}[name]()
+    before = _hip.set_write_through_mib(0)
+    try:
+        for E in (16, 1000, 30_001, 100_000, 100_003, 150_000):
+            g = torch.Generator(device="cuda").manual_seed(E)
+            dev = {a: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[a]), dtype=torch.float64,
+                                 device="cuda", generator=g) for a in sorted(expr.all_args)}
+            shape = tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.shape)
+            results = []
+            for mib in (0, 1 << 20):
+                _hip.set_write_through_mib(mib)
+                outs = {n: torch.full(shape, float("nan"), dtype=torch.float64, device="cuda") for n in expr.output_names}
+                f.evaluate(expr, 0, dev, out_dict=outs, wait=True)
+                results.append(outs)
+            for n in expr.output_names:
+                assert not torch.isnan(results[1][n]).any(), (name, E, n)
+                assert torch.equal(results[0][n], results[1][n]), (name, E, n)
+    finally:
+        assert _hip.set_write_through_mib(before) == 1 << 20
