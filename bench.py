@@ -709,6 +709,22 @@ def main() -> None:
     finally:
         _hip.set_temporal_loads_mib(mib_setting)
 
+    # A/B outside the timed region: the output stores the other way (write-through in short grad launches -- static walk, outputs
+    # of at most fe_set_write_through_mib MiB -- non-temporal otherwise: feinsum_amd/csrc/fe_common.h)
+    out_bytes = sum(int(t.numel()) * t.element_size() for t in outs_all)
+    wt_setting = _hip.set_write_through_mib(0)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    static_launch = rounds_setting < 0 or (E // 16) // (8 * cus) < 5         # (the launcher's rule for p = 4: fewer than five rounds)
+    write_through = args.workload == "grad" and 0 < out_bytes <= (wt_setting << 20) and static_launch
+    stores_report = {"threshold_mib": wt_setting, "launch_output_mib": round(out_bytes / 2**20, 1),
+                     "policy": "write-through (a short launch: nothing dirty left in the L2s at its end)" if write_through else "non-temporal"}
+    try:
+        if not args.no_protocol and write_through:
+            step_batch(max(args.warmup, 10))
+            stores_report["kernel_ms_non_temporal_stores"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
+    finally:
+        _hip.set_write_through_mib(wt_setting)
+
     total, reduction_ms, allgather_ms = exchange_results(outs_all, sync)
     finite = bool(torch.isfinite(total).all().item()) and bool((total[:, 1] > 0).all().item())
 
@@ -731,7 +747,7 @@ def main() -> None:
                  "result_finite": finite, "kernel_source_sha": kernel_source_sha(),
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
-                 "walk": walk_report, "loads": loads_report,
+                 "walk": walk_report, "loads": loads_report, "stores": stores_report,
                  "dist_backend": info.backend if parallel.in_group() else None,
                  # the optional full-field exchange runs BEHIND this line (rank 0 reports it on stderr): whatever happens
                  # inside a 6.7 GB-per-GPU collective cannot cost the scaling record

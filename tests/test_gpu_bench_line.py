@@ -37,6 +37,8 @@ def test_bench_line_single_process(workload):
     assert line["dist_backend"] is None and line["value"] > 0
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # 20 000 elements: one round, static walk -- grad stores write-through, the fused pipeline does not (fe_common.h)
+    assert line["stores"]["policy"].startswith("write-through" if workload == "grad" else "non-temporal"), line["stores"]
 
 
 @pytest.mark.gpu
