@@ -688,7 +688,7 @@ def main() -> None:
             static_walk_ms = step_batch(args.steps) / args.steps * 1e3
     finally:
         _hip.set_tail_rounds(rounds_setting)
-    walk_report = {"mode": "static" if rounds_setting < 0 else "tickets behind two static rounds (launches of five or more rounds)",
+    walk_report = {"mode": "static" if rounds_setting < 0 else "tickets behind two static rounds (launches of four and a half or more rounds)",
                    "dynamic_rounds": "all" if rounds_setting >= (1 << 20) else rounds_setting,
                    "kernel_ms_static_walk": None if static_walk_ms is None else round(static_walk_ms, 5)}
 
@@ -714,7 +714,8 @@ def main() -> None:
     out_bytes = sum(int(t.numel()) * t.element_size() for t in outs_all)
     wt_setting = _hip.set_write_through_mib(0)
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    static_launch = rounds_setting < 0 or (E // 16) // (8 * cus) < 5         # (the launcher's rule for p = 4: fewer than five rounds)
+    tiles, waves = E // 16, 8 * cus                                           # (the launcher's rule for p = 4: feinsum_hip.hip, tail_static_tiles)
+    static_launch = rounds_setting < 0 or tiles // waves < 4 or (tiles // waves == 4 and (tiles - 4 * waves) * 2 < waves)
     write_through = args.workload == "grad" and 0 < out_bytes <= (wt_setting << 20) and static_launch
     stores_report = {"threshold_mib": wt_setting, "launch_output_mib": round(out_bytes / 2**20, 1),
                      "policy": "write-through (a short launch: nothing dirty left in the L2s at its end)" if write_through else "non-temporal"}

@@ -158,7 +158,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //    pool's waves to do so zeroes both: the counters are all zero between launches, whatever stream or graph replays the
 //    launch.  (One report counter for the whole grid was measured first: 2048 atomics on one address take ~23 us, E = 1e5
 //    went from 24 to 40 us.)
-// Below five rounds (E = 1e5: three) the static walk is faster (61.1 against 57.5 %) and stays.  Results do not depend on the
+// Below four and a half rounds (E = 1e5: three) the static walk is faster (61.1 against 57.5 %) and stays.  Results do not depend on the
 // walk: a tile's arithmetic is position independent (bitwise equal outputs: tests/test_gpu_parity.py).
 constexpr int kTailPools = 16;
 constexpr int kTailStride = 2176;                        // unsigned per pool: tickets, and 4352 bytes behind them the reports

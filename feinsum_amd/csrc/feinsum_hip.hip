@@ -262,7 +262,7 @@ unsigned* tail_slot(hipStream_t s, int sets = 1) {
 }
 // Number of statically walked tiles of a launch of `blocks` blocks of `waves / blocks` waves: two rounds, the rest by
 // tickets (FEINSUM_TAIL_ROUNDS / fe_set_tail_rounds: at most so many full rounds by tickets; negative: none); launches of
-// fewer than five rounds walk statically (E = 1e5 on 2048 waves: three rounds, measured slower with tickets), and so do
+// fewer than four and a half rounds walk statically (E = 1e5 on 2048 waves: three rounds, measured slower with tickets), and so do
 // grids of fewer than 8 blocks per pool: a block's pool is (bid / 8) % kTailPools and nobody steals, so that a pool
 // without blocks would keep its tiles (a 32-CU partition launches 64 blocks).
 std::atomic<int> g_tail_rounds{[] { const char* e = getenv("FEINSUM_TAIL_ROUNDS"); return e ? atoi(e) : (1 << 20); }()};
@@ -271,7 +271,11 @@ int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock) {
     const int64_t waves = blocks * wavesPerBlock;
     const int64_t rounds = waves > 0 ? nTiles / waves : 0;
     if (blocks < 8 * fe::kTailPools) return nTiles;
-    if (dyn_rounds < 0 || rounds < 5 || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
+    if (dyn_rounds < 0 || rounds < 4 || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
+    // four rounds and a bit: tickets pay once the partial fifth round is at least half a round -- a static walk leaves those waves
+    // a tile behind the rest (div E = 163 000: 41.2 -> 37.7 us; grad 150 000: 34.4 -> 33.5), while four EXACT rounds are perfectly
+    // balanced as they are (grad 131 072: 28.6 static, 30.7 with tickets; profiles/r04/dynamic_walk_from_four_and_a_half_rounds.txt)
+    if (rounds == 4 && (nTiles - 4 * waves) * 2 < waves) return nTiles;
     int64_t ks = rounds - dyn_rounds;
     if (ks < 2) ks = 2;
     return ks * waves;

@@ -793,7 +793,7 @@ def test_dynamic_walk_gives_the_bits_of_the_static_walk(torch_cuda, name):
     expr = {"grad": dg.grad, "div": dg.div, "face_mass": lambda: dg.face_mass(4), "face_mass_b3": lambda: dg.face_mass(3),
             "batched_div_b2": lambda: dg.batched_div(2), "batched_div_b3": lambda: dg.batched_div(3),
             "batched_grad_b2": lambda: dg.batched_grad(2), "batched_grad_b3": lambda: dg.batched_grad(3)}[name]()
-    sizes = [163_840, 163_856, 200_003, 700_001, 163_840, 1_000_000, 180_000]
+    sizes = [163_840, 163_856, 200_003, 700_001, 163_840, 1_000_000, 180_000, 155_003, 147_456, 147_440]   # (the last three: four and a half rounds)
     before = _hip.set_tail_rounds(1 << 20)
     try:
         for E in sizes:
