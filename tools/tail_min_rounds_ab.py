@@ -1,3 +1,6 @@
+"""Launch times around the switch between the static and the dynamic walk (four and a half rounds: feinsum_hip.hip, tail_static_tiles).
+   python tools/tail_min_rounds_ab.py          (profiles/r04/dynamic_walk_from_four_and_a_half_rounds.txt was taken with an
+   experiment knob, FEINSUM_TAIL_MIN_ROUNDS, that the rule has since replaced: the label it prints is that variable)"""
 import os, sys
 sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
 import torch
