@@ -147,6 +147,29 @@ __device__ __forceinline__ void div3d_mfma_body(
     double abig[(G::BT > 0 && !ALDS) ? G::BT : 1][ALDS ? 1 : G::KSJ][ALDS ? 1 : NC];
     double* asmall = reinterpret_cast<double*>(smem + (G::LDS_BYTES - (G::ASMALL_D + G::ABIG_D) * 8));
     double* afr = asmall + G::ASMALL_D;   // ALDS: big-tile fragments [(jq * NC + r) * BT + t][lane]
+    // The elements behind the last full tile (fe_common.h: remainder_items), entry by entry on the VALU, with the operator read from
+    // `Dsrc`: the block's LDS copy while it exists (see fe_grad.h), else global memory.
+    auto remainder = [&](const double* Dsrc) {
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+            for (int k = 0; k < nb; ++k) {
+                const double* uk = field_in(P, k);
+                double* ok = field_out(P, k);
+                if (MODE == 0 && ND == 3) div3d_item(J, Dsrc, uk, ok, E, NP, e, i, opT);
+                else if (MODE == 0) div_nd_item(J, Dsrc, uk, ok, E, NP, ND, e, i, opT);
+                else if (MODE == 4) grad_nd_item(J, Dsrc, uk, ok, E, NP, ND, e, i, opT);
+                else if (MODE == 5) {
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        double* ox = grad_plane_out(*Q, k, x);
+                        if (ox) divcomp3d_item(Q->j[x], Dsrc, uk, ox, E, NP, e, i, opT, 0);
+                    }
+                }
+                else if (MODE == 1 && ND == 3) divcomp3d_item(J, Dsrc, uk, ok, E, NP, e, i, opT, jes);
+                else if (MODE == 1) divcomp_nd_item(J, Dsrc, uk, ok, E, NP, ND, e, i, opT, jes);
+                else matapply_item(MODE == 2 ? J : nullptr, Dsrc, uk, ok, NP, e, i, opT);
+            }
+        });
+    };
     if constexpr (!kPrep) {
         double* dl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D, G::THREADS>(D, dl);
@@ -174,7 +197,13 @@ __device__ __forceinline__ void div3d_mfma_body(
             const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
             asmall[idx] = (j < NP && i < NP) ? dl[r * (NP * NP) + i * istride + j * jstride] : 0.0;
         }
+        // (while the block's copy of the operator is still there; not in the eight-wave p = 5 kernels, whose prologue has no registers
+        //  to spare: the compiler took the ticket registers for it -- tests/test_ticket_registers.py)
+        if constexpr (!ALDS && !W8) remainder(dl);
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
+        if constexpr (ALDS || W8) remainder(D);
+    } else {
+        remainder(D);
     }
     const double* as_lane = asmall + g * 4 + (n & 3);
     const double* af_lane = afr + lane;
@@ -183,25 +212,6 @@ __device__ __forceinline__ void div3d_mfma_body(
         else return abig[t][jq][r];
     };
 
-    remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
-        for (int k = 0; k < nb; ++k) {
-            const double* uk = field_in(P, k);
-            double* ok = field_out(P, k);
-            if (MODE == 0 && ND == 3) div3d_item(J, D, uk, ok, E, NP, e, i, opT);
-            else if (MODE == 0) div_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
-            else if (MODE == 4) grad_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT);
-            else if (MODE == 5) {
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    double* ox = grad_plane_out(*Q, k, x);
-                    if (ox) divcomp3d_item(Q->j[x], D, uk, ox, E, NP, e, i, opT, 0);
-                }
-            }
-            else if (MODE == 1 && ND == 3) divcomp3d_item(J, D, uk, ok, E, NP, e, i, opT, jes);
-            else if (MODE == 1) divcomp_nd_item(J, D, uk, ok, E, NP, ND, e, i, opT, jes);
-            else matapply_item(MODE == 2 ? J : nullptr, D, uk, ok, NP, e, i, opT);
-        }
-    });
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);

@@ -145,6 +145,17 @@ __device__ __forceinline__ void facemass_mfma_body(
         voff[ks] = f * G::SLAB_D + n * NFP + j;
         joff[ks] = jfe ? f * G::TEL + n : n * NF + f;
     }
+    // The elements behind the last full tile (fe_common.h: remainder_items), entry by entry on the VALU, with the operator read from
+    // `Rsrc`: the block's LDS copy while it exists (see fe_grad.h), else global memory.
+    auto remainder = [&](const double* Rsrc) {
+        const int64_t jEs = jfe ? 1 : NF, jFs = jfe ? E : 1;
+        const int rF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
+        const int rI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
+        const int rJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : NF * NP;
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+            facemass_item<NB>(J, Rsrc, P, E, NP, NF, NFP, jEs, jFs, rF, rI, rJ, e, i);
+        });
+    };
     if constexpr (kPrep) {
         load_prepared_fragments<(G::BT + G::NS) * G::KS>(reinterpret_cast<const char*>(prep) + kPrepFmOff, lane,
                                                        [&](int f, double v) {
@@ -188,8 +199,10 @@ __device__ __forceinline__ void facemass_mfma_body(
                 }
             }
         }
+        if constexpr (!ALDS && !W8) remainder(rl);   // (while the block's copy of the operator is still there; see fe_div.h)
         __syncthreads();   // the staging area is reused as the waves' private buffers from here on
     }
+    if constexpr (kPrep || ALDS || W8) remainder(R);
 
     const double* af_lane = afr + lane;
     const double* as_lane = afs + g * 4 + (n & 3);
@@ -206,15 +219,6 @@ __device__ __forceinline__ void facemass_mfma_body(
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
     const int64_t first = (int64_t)bid * G::WAVES + wave;
-    {
-        const int64_t jEs = jfe ? 1 : NF, jFs = jfe ? E : 1;
-        const int rF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
-        const int rI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
-        const int rJ = rlayout == 0 || rlayout == 1 ? 1 : rlayout == 2 ? NP : NF * NP;
-        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
-            facemass_item<NB>(J, R, P, E, NP, NF, NFP, jEs, jFs, rF, rI, rJ, e, i);
-        });
-    }
     if (first >= tEnd) return;
 
     if constexpr (W8) {

@@ -257,10 +257,29 @@ __device__ __forceinline__ void grad3d_mfma_body(
         }
         return 3;
     };
+    // The elements behind the last full tile (fe_common.h: remainder_items), entry by entry on the VALU -- with the operator read from
+    // `Dsrc`: the block's LDS copy while it exists (lanes walk i, 280 bytes apart: from global memory every load instruction touches
+    // 35 cache lines, ~1.7 us per wave for the 105 of an entry; from LDS they are 2-way bank conflicts), else global memory.
+    auto remainder = [&](const double* Dsrc) {
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
+            for (int k = 0; k < nb; ++k) {
+                const double* uk = grad_field_u(P, k);
+                if (kPlain) {
+                    grad3d_item(P.j[0], Dsrc, uk, grad_plane_out(P, k, 0), E, NP, e, i, opT);
+                } else {
+                    double* const o[3] = {grad_plane_out(P, k, 0), grad_plane_out(P, k, 1), grad_plane_out(P, k, 2)};
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+                        if (o[x]) divcomp3d_item(P.j[x], Dsrc, uk, o[x], E, NP, e, i, opT, 0);
+                }
+            }
+        });
+    };
     if constexpr (kPrep) {
         load_prepared_fragments<G::RT * G::KS>(prep, lane, [&](int f, double v) { afrag[f / G::KS][f % G::KS] = v; });
         issue_first_units();
         prepared_fragments_landed();
+        remainder(D);
     } else {
         // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
         stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
@@ -309,25 +328,13 @@ __device__ __forceinline__ void grad3d_mfma_body(
             fe_dbg_phase[bid * G::WAVES + wave][2] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
+        remainder(dl);     // (while the block's copy of the operator is still there)
         __syncthreads();   // the staging area becomes the waves' output buffers
 #ifdef FE_EXPERIMENTS
         if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][3] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
 
-    remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
-        for (int k = 0; k < nb; ++k) {
-            const double* uk = grad_field_u(P, k);
-            if (kPlain) {
-                grad3d_item(P.j[0], D, uk, grad_plane_out(P, k, 0), E, NP, e, i, opT);
-            } else {
-                double* const o[3] = {grad_plane_out(P, k, 0), grad_plane_out(P, k, 1), grad_plane_out(P, k, 2)};
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-                    if (o[x]) divcomp3d_item(P.j[x], D, uk, o[x], E, NP, e, i, opT, 0);
-            }
-        }
-    });
 
     // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
     auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt) {
