@@ -16,7 +16,7 @@
 // ring of two 0.1222 ms, ring of two with rows 32..34 on the 4x4x1 instruction 0.1094 ms = 73.0 TFLOP/s = 68.1 %.
 // 596 B and 7980 flops per element: HBM roofline 107 TFLOP/s.  Operands must be 16-byte aligned with E a multiple of 4 (every
 // plane and every row of J then starts on a 16-byte boundary; the launcher sends other sizes to the tiled kernel); the
-// elements behind the last full tile are done by block 0.
+// elements behind the last full tile: remainder_items (fe_common.h).
 #pragma once
 #include "fe_grad_f32.h"
 
@@ -148,12 +148,11 @@ __global__ __launch_bounds__(256, RING == 1 ? 3 : 2) void div3d_mfma_f32_kernel(
             }
         }
     }
-    __syncthreads();   // the staging area becomes the waves' output buffers
-
-    if (bid == 0) {
-        const int64_t e_begin = nTiles * G::TEL, cnt = (E - e_begin) * NP;
-        for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) div3d_item_f32(J, D, u, out, E, NP, e_begin + idx / NP, (int)(idx % NP), opT);
+    {   // the elements behind the last full tile, with the operator from the block's LDS copy (see fe_grad_f32.h)
+        const float* dl = reinterpret_cast<const float*>(smem + G::IN_BYTES);
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) { div3d_item_f32(J, dl, u, out, E, NP, e, i, opT); });
     }
+    __syncthreads();   // the staging area becomes the waves' output buffers
 
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, slot = 0;

@@ -13,7 +13,7 @@
 // Twelve waves per CU (40 KB of LDS per block of four).  The number of fields is a run-time argument (1..8): units are walked
 // (tile, field), field fastest.
 // 1536 B and 17 040 flops per element at four fields: HBM roofline 88.7 TFLOP/s.  Operands must be 16-byte aligned with E a
-// multiple of 4; the elements behind the last full tile are done by block 0.
+// multiple of 4; the elements behind the last full tile: remainder_items (fe_common.h).
 #pragma once
 #include "fe_grad_f32.h"
 
@@ -133,26 +133,23 @@ __global__ __launch_bounds__(256, 3) void facemass_mfma_f32_kernel(const float* 
             }
         }
     }
-    __syncthreads();   // the staging area becomes the waves' output buffers
-
-    if (bid == 0) {
-        const int64_t e_begin = nTiles * G::TEL, cnt = (E - e_begin) * NP;
+    {   // the elements behind the last full tile, with the operator from the block's LDS copy (see fe_grad_f32.h)
+        const float* rl = reinterpret_cast<const float*>(smem + G::IN_BYTES);
         const int64_t jEs = jfe ? 1 : NF, jFs = jfe ? E : 1;
-        for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) {
-            const int64_t e = e_begin + idx / NP;
-            const int i = (int)(idx % NP);
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) {
             for (int k = 0; k < nb; ++k) {
                 const float* vk = field_in_f32(P, k);
                 float acc = 0.f;
                 for (int f = 0; f < NF; ++f) {
                     const float jf = J[e * jEs + f * jFs];
                     for (int j = 0; j < NFP; ++j)
-                        acc = __builtin_fmaf(R[f * sF + i * sI + j * sJ], jf * vk[((int64_t)f * E + e) * NFP + j], acc);
+                        acc = __builtin_fmaf(rl[f * sF + i * sI + j * sJ], jf * vk[((int64_t)f * E + e) * NFP + j], acc);
                 }
                 field_out_f32(P, k)[e * NP + i] = acc;
             }
-        }
+        });
     }
+    __syncthreads();   // the staging area becomes the waves' output buffers
 
     int slot = 0, done = 0, iteration = 0;
     float jv[G::KS];

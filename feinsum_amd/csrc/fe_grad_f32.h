@@ -12,7 +12,7 @@
 // Half the bytes of float64 per element (596 + 14 700 once), so the HBM roofline in GFLOP/s doubles: 107 TFLOP/s.
 // The reference validates float32 einsums at 1e-6 (src/feinsum/measure.py:178-192).
 // Operands must be 16-byte aligned with E a multiple of 4 (every row and plane then starts on a 16-byte boundary; the
-// launcher sends other sizes to the tiled kernel); the elements behind the last full tile are done by block 0.
+// launcher sends other sizes to the tiled kernel); the elements behind the last full tile: remainder_items.
 #pragma once
 #include "fe_common.h"
 #include "fe_grad.h"   // grad_row_tiles
@@ -172,13 +172,13 @@ __device__ __forceinline__ void grad3d_mfma_f32_body(const float* __restrict__ J
             }
         }
     }
-    __syncthreads();   // the staging area becomes the waves' output buffers
-
-    // the elements behind the last full tile: block 0, plain code
-    if (bid == 0) {
-        const int64_t e_begin = nTiles * G::TEL, cnt = (E - e_begin) * NP;
-        for (int64_t idx = threadIdx.x; idx < cnt; idx += 256) grad3d_item_f32(J, D, u, out, E, NP, e_begin + idx / NP, (int)(idx % NP), opT);
+    // the elements behind the last full tile: plain code, one entry per thread on a few blocks (fe_common.h: remainder_items), while the
+    // block's LDS copy of the operator is still there (from global memory each of an entry's operator loads touches 35 cache lines)
+    {
+        const float* dl = reinterpret_cast<const float*>(smem + G::IN_BYTES);
+        remainder_items(nTiles * G::TEL, E, NP, bid, nblk, [&](int64_t e, int i) { grad3d_item_f32(J, dl, u, out, E, NP, e, i, opT); });
     }
+    __syncthreads();   // the staging area becomes the waves' output buffers
 
     // one tile: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
     auto compute_tile = [&](int64_t tile_, const float* ut, const float* jt) {
