@@ -95,8 +95,17 @@ def rank_elements(args, info) -> int:
 
 
 def timed_region(step_batch, steps: int, sync, device=None):
-    """barrier + sync | K steps | barrier + sync; returns (wall seconds, kernel seconds), both the
-    MAX over ranks.  *step_batch(n)* enqueues n steps and returns their device seconds."""
+    """barrier + sync | K steps | sync | barrier + sync.  *step_batch(n)* enqueues n steps and returns their device
+    seconds.  Returns a dict of seconds:
+
+    ``wall``            MAX over ranks of each rank's own [after the opening barrier, its own K steps done and synchronised]
+                        -- the sharded path has no data-path collective, so this is when the job's work is done;
+    ``wall_barrier``    MAX over ranks of the same interval extended over the closing barrier + synchronize (one more
+                        collective: 50-200 us of RCCL all-reduce and Python, 1-5 % of a 3.8 ms region -- reported, not charged
+                        to the kernels);
+    ``kernel``          MAX over ranks of the device seconds of the K steps (HIP events on the launch stream);
+    ``local_wall`` / ``local_kernel``   this rank's own two figures.
+    """
     from feinsum_amd import parallel
 
     sync()
@@ -105,10 +114,33 @@ def timed_region(step_batch, steps: int, sync, device=None):
     t0 = time.perf_counter()
     kernel_s = step_batch(steps)
     sync()
+    local_s = time.perf_counter() - t0
     parallel.barrier()
     sync()
-    wall_s = time.perf_counter() - t0
-    return parallel.max_over_ranks(wall_s, device), parallel.max_over_ranks(kernel_s, device)
+    closed_s = time.perf_counter() - t0
+    return {"wall": parallel.max_over_ranks(local_s, device), "wall_barrier": parallel.max_over_ranks(closed_s, device),
+            "kernel": parallel.max_over_ranks(kernel_s, device), "local_wall": local_s, "local_kernel": kernel_s}
+
+
+_PLACEMENT_MODES = ("split", "separate", "separate (split allocator failed)")
+
+
+def gather_rank_reports(report: dict, device=None) -> list:
+    """Every rank's own figures in rank 0's line (one all-gather of a few doubles): elements, kernel and wall milliseconds
+    per step of ITS timed steps, and what its allocator did -- `value` is the job's flops over the SLOWEST rank's time, so a
+    rank on unsplit arrays or with a ten-second search must be attributable.  *report*: ``elements``, ``kernel_ms``,
+    ``wall_ms``, ``placement_mode`` (one of _PLACEMENT_MODES), ``unsplit_arrays``, ``allocator_ms``."""
+    from feinsum_amd import parallel
+
+    mode = report.get("placement_mode", "separate")
+    row = [report["elements"], report["kernel_ms"], report["wall_ms"], _PLACEMENT_MODES.index(mode) if mode in _PLACEMENT_MODES else 1,
+           report.get("unsplit_arrays", 0), report.get("allocator_ms", 0.0), report.get("search_ms", 0.0)]
+    out = []
+    for rank, r in enumerate(parallel.gather_rows(row, device)):
+        out.append({"rank": rank, "elements": int(r[0]), "kernel_ms": round(r[1], 5), "wall_ms": round(r[2], 5),
+                    "placement_mode": _PLACEMENT_MODES[int(r[3])], "unsplit_arrays": int(r[4]), "allocator_ms": round(r[5], 1),
+                    "allocator_search_ms": round(r[6], 1)})
+    return out
 
 
 def exchange_results(outs, sync):
@@ -218,7 +250,7 @@ def committed_counters(workload: str, E: int):
     """HBM bytes per launch and MFMA utilisation from profiles/traffic_<workload>.json (rocprofv3
     --pmc passes, tools/pmc_summary.py) -- only if that profile was taken at this element count on
     a library built from exactly these kernel sources; otherwise (None, note)."""
-    tfile = ROOT / "profiles" / f"traffic_{workload}.json"
+    tfile = ROOT / "profiles" / (f"traffic_{workload}.json" if E == 1_000_000 else f"traffic_{workload}_E{E}.json")
     try:
         rec = json.loads(tfile.read_text())
     except (OSError, ValueError):
@@ -528,8 +560,19 @@ def main() -> None:
     # several ranks start their allocator searches at the same instant, each on its own device but through one driver: bound
     # what a search for a second class of memory may take (default 4 s; the arrays are then of one class and say so --
     # `placement.pool.unsplit_arrays` in the line -- and run like ordinary allocations)
+    # (round 5: the budget is the pool's TOTAL, wall clock, release of the skipped memory included -- fe_split_alloc.h; round 4's
+    # bounded the spacer creation of one search and let a 10 s search through in the four-rank rehearsal)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         os.environ.setdefault("FEINSUM_SPLIT_SEARCH_MS", "2500")
+        os.environ.setdefault("FEINSUM_SPLIT_SEARCH_GIB", "32")
+        try:       # ranks that share a device (rehearsals) search their share of its free memory only; counting devices does not
+            import torch as _t   # initialise the GPU
+
+            n_dev = max(_t.cuda.device_count(), 1)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+            os.environ.setdefault("FEINSUM_SPLIT_SHARE", str(max(1, -(-local_world // n_dev))))
+        except Exception:   # noqa: BLE001
+            pass
 
     # a kernel that compiled to fewer resident blocks per CU than its launch geometry assumes is an error here, not a
     # warning (feinsum_hip.hip: configure_kernel): a number taken at half the residency is not the product's
@@ -619,8 +662,10 @@ def main() -> None:
                 "output_mapped_bytes": sum(i.get("mapped_bytes", 0) for i in infos),
                 "allocator_ms": round(pool["setup_ms"] + pool["alloc_ms_total"], 3),
                 "inputs_and_outputs_ready_ms": round(t_alloc, 1),
-                "pool": {k: pool[k] for k in ("classes", "pieces_created", "groups_probed", "probes", "probe_ms", "spacers_created", "spacer_bytes_peak", "spacer_ms", "groups_discarded",
-                                                "unsplit_arrays", "pooled_bytes", "walk_gave_up")},
+                "pool": {k: pool.get(k) for k in ("classes", "pieces_created", "groups_probed", "probes", "probe_ms", "spacers_created", "spacer_bytes_peak", "spacer_ms",
+                                                    "search_ms", "search_ms_budget", "release_ms", "groups_discarded", "unsplit_arrays", "pooled_bytes", "walk_gave_up")},
+                # an output whose pieces are all of ONE class runs like an ordinary allocation: not a split-placement result
+                "degraded": bool(pool.get("unsplit_arrays", 0)),
             }
     else:
         stages, out_dicts = separate_allocations()
@@ -648,7 +693,14 @@ def main() -> None:
 
     step_batch = step_batch_of(op)
 
-    wall_s, kernel_s = timed_region(step_batch, args.steps, sync, device)
+    timed = timed_region(step_batch, args.steps, sync, device)
+    wall_s, kernel_s = timed["wall"], timed["kernel"]
+    pool_r = placement_report.get("pool") or {}
+    per_rank = gather_rank_reports({"elements": E, "kernel_ms": timed["local_kernel"] / args.steps * 1e3, "wall_ms": timed["local_wall"] / args.steps * 1e3,
+                                    "placement_mode": ("split" if placement_report.get("mode") == "split" else
+                                                       "separate (split allocator failed)" if "fallback" in placement_report else "separate"),
+                                    "unsplit_arrays": pool_r.get("unsplit_arrays", 0) or 0, "allocator_ms": placement_report.get("allocator_ms", 0.0),
+                                    "search_ms": pool_r.get("search_ms", 0.0) or 0.0}, device)
 
     # the reference's own protocol on the same bound launch (every rank, no barrier inside)
     protocol_ms = None
@@ -749,6 +801,10 @@ def main() -> None:
                  "operator_prepared": prepared, "placement": placement_report,
                  "kernel_ms_separate_allocations": None if separate_ms is None else round(separate_ms, 5),
                  "walk": walk_report, "loads": loads_report, "stores": stores_report,
+                 # `value` / `ms_per_step`: MAX over ranks of each rank's own time to its own synchronize (no data-path
+                 # collective to wait for); the same region with the closing barrier + synchronize inside, for comparison:
+                 "ms_per_step_barrier_inclusive": round(timed["wall_barrier"] / args.steps * 1e3, 5),
+                 "per_rank": per_rank,
                  "dist_backend": info.backend if parallel.in_group() else None,
                  # the optional full-field exchange runs BEHIND this line (rank 0 reports it on stderr): whatever happens
                  # inside a 6.7 GB-per-GPU collective cannot cost the scaling record

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
     "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
-    "fe_set_cu_limit", "fe_stream_retired", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
+    "fe_set_cu_limit", "fe_set_wide_blocks", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -177,10 +177,18 @@ def load_library() -> C.CDLL:
     lib.fe_set_write_through_mib.argtypes = [C.c_int32]
     lib.fe_set_cu_limit.restype = C.c_int
     lib.fe_set_cu_limit.argtypes = [C.c_int32]
+    lib.fe_set_wide_blocks.restype = C.c_int
+    lib.fe_set_wide_blocks.argtypes = [C.c_int64]
     lib.fe_stream_retired.restype = C.c_int
     lib.fe_stream_retired.argtypes = [C.c_void_p]
     lib.fe_tail_plant.restype = C.c_int
     lib.fe_tail_plant.argtypes = [C.c_void_p, C.c_uint32]
+    lib.fe_capture_id.restype = C.c_int
+    lib.fe_capture_id.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.fe_graph_retired.restype = C.c_int
+    lib.fe_graph_retired.argtypes = [C.c_uint64]
+    lib.fe_tail_stats.restype = C.c_int
+    lib.fe_tail_stats.argtypes = [C.POINTER(C.c_int64), C.c_int32]
     lib.fe_tail_check.restype = C.c_int
     lib.fe_tail_check.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]
@@ -442,9 +450,45 @@ def tail_check(repair: bool = False) -> dict:
             "captured": int(captured.value)}
 
 
+_TAIL_STATS = ("groups", "streams", "captured", "spare", "exhausted", "static_fallbacks", "grow_failures", "verified_after_error",
+               "repaired_after_error", "live_captures", "max_groups", "hip_errors")
+
+
+def tail_stats() -> dict:
+    """Counters of the ticket-counter pool of the current device (fe_tail_stats): ``exhausted`` / ``static_fallbacks`` say how
+    many launches that wanted tickets walked statically instead."""
+    buf = (C.c_int64 * len(_TAIL_STATS))()
+    n = int(load_library().fe_tail_stats(buf, len(_TAIL_STATS)))
+    if n < 0:
+        check(n)
+    return {k: int(buf[i]) for i, k in enumerate(_TAIL_STATS[:n])}
+
+
+def capture_id(stream: int) -> int:
+    """Id of the stream capture in progress on *stream* (fe_capture_id; 0: not capturing)."""
+    cid = C.c_uint64()
+    check(load_library().fe_capture_id(stream, C.byref(cid)))
+    return int(cid.value)
+
+
+def graph_retired(cid: int) -> int:
+    """The graph captured under *cid* and its executables are gone: its launches' counter groups may serve others
+    (fe_graph_retired); returns how many groups came back."""
+    rc = int(load_library().fe_graph_retired(int(cid)))
+    if rc < 0:
+        check(rc)
+    return rc
+
+
 def tail_plant(stream: int, value: int) -> None:
     """Test hook (fe_tail_plant): leave a stale ticket in the counter group of *stream*."""
     check(load_library().fe_tail_plant(stream, int(value)))
+
+
+def set_wide_blocks(tiles: int) -> int:
+    """p = 4 grad / div launches (one field) of at most *tiles* 16-element tiles run on the sixteen-waves-per-CU kernels
+    (fe_set_wide_blocks; 0 = never, 1 = always); returns the previous setting.  A tuning knob."""
+    return int(load_library().fe_set_wide_blocks(int(tiles)))
 
 
 def set_write_through_mib(mib: int) -> int:

@@ -273,10 +273,17 @@ __device__ __forceinline__ void div3d_mfma_body(
         const unsigned lds_a = lds_addr_uniform(L->u[0]), lds_b = lds_addr_uniform(L->u[W8 ? 0 : 1]);
         auto issue_plane = [&](int64_t t, int fk, int x, unsigned lds) {
             const char* up = reinterpret_cast<const char*>(field_in(P, fk)) + ((int64_t)x * E + t * G::TEL) * (NP * 8);
+            if (tload) {   // (fe_common.h, kOpLoadsTemporal: one scalar branch for the whole plane)
 #pragma unroll
-            for (int c = 0; c < G::P_INSTR; ++c)
-                if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
-                    glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds + c * 1024);
+                for (int c = 0; c < G::P_INSTR; ++c)
+                    if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                        glds16(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds + c * 1024);
+            } else {
+#pragma unroll
+                for (int c = 0; c < G::P_INSTR; ++c)
+                    if ((c + 1) * 64 <= G::P_CHUNKS || c * 64 + lane < G::P_CHUNKS)
+                        glds16_nt(up + tile_src_chunk<NP>(c * 64 + lane) * 16, lds + c * 1024);
+            }
         };
         auto issue_j = [&](int64_t t) {
             const char* jb = reinterpret_cast<const char*>(J) + t * G::TEL * 8;
@@ -778,6 +785,14 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
+    int dbg_it = 0;   // (experiments build: units done by this wave, for the per-tile stamps of kDbg & 128)
+#ifdef FE_EXPERIMENTS
+    unsigned long long dbg_entry = 0;
+    if (kDbg & 128) {
+        dbg_entry = __builtin_amdgcn_s_memrealtime();
+        if (lane < 16) reinterpret_cast<unsigned long long*>(smem + G::LDS_BYTES)[wave * 16 + lane] = 0;
+    }
+#endif
     // dynamic walk (plain walk): vector-memory ops of a unit in issue order [ticket or report] L(next unit) S(this unit), so the
     // counted wait at the top of a unit is that of the static walk.  One field: the ticket asked for in front of L(next) is for
     // the tile after next and is read one iteration later at the same place.  b fields (units (tile, field), field fastest):
@@ -799,6 +814,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         if (first || (kDbg & 10)) wait_vmcnt<0>();
         else wait_vmcnt<G::STORES>();
         first = false;
+        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
 
         // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
         double bfrag[M][G::KSJ][G::NBF];
@@ -888,6 +904,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
         }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
+        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // B fragments built, the next unit's loads issued
         if constexpr ((kDbg & 64) != 0 && MODE == 0 && ND == 3 && M == 1) {
             // experiment (kDbg & 64): touch the tile AFTER next -- one dword per 128-byte line of its three planes and nine J rows --
             // so that its LDS-DMA loads, which can only go out one MFMA phase ahead of their use, find the lines in the L2
@@ -1002,6 +1019,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     }
             }
 
+            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
             // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e][16t + g + 4q'];
             //      4x4x4_4b D of group q: lane (g, n) holds out[e][16 BT + 4q + g]
             double* ob = L->o;
@@ -1027,9 +1045,23 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
             wave_lds_fence();
         }
+        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
+        ++dbg_it;
         fk = nk;
         tile = nt;
     }
+#ifdef FE_EXPERIMENTS
+    if (kDbg & 128) {   // stamps out: the tile stamps, and {kernel entry, -, loop end, XCC_ID | HW_ID << 8 | tiles << 40} as fe_grad.h
+        const int w = bid * G::WAVES + wave;
+        FE_TILE_STAMPS_OUT(true, smem + G::LDS_BYTES, wave, lane, w);
+        if (lane == 0 && w < 4096) {
+            fe_dbg_stamps[w][0] = dbg_entry; fe_dbg_stamps[w][1] = dbg_entry; fe_dbg_stamps[w][2] = __builtin_amdgcn_s_memrealtime();
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            fe_dbg_stamps[w][3] = xcc | ((unsigned long long)hw << 8) | ((unsigned long long)dbg_it << 40);
+        }
+    }
+#endif
     if constexpr (kDyn) {
         // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch
         if (reported) {
@@ -1087,6 +1119,14 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void div3d_mfma_kernel(
     int64_t E, int64_t nTiles, int opT, int jes) {
     div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8, kPrep>(J, D, prep, P, nb, E, nTiles, opT, jes, blockIdx.x,
                                                             gridDim.x);
+}
+
+// EXPERIMENT (round 5): the eight-wave kernels (A in LDS) at p = 4 with TWO blocks per CU = four waves per SIMD, for short
+// launches: with two waves per SIMD and three tiles per wave the matrix pipe idles whenever both are between MFMA phases
+template <int NP, int MODE>
+__global__ __launch_bounds__(512, 4) void wide_w8_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT) {
+    div3d_mfma_body<NP, 1, 0, MODE, 3, true, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x);
 }
 
 // grad-type planes at p = 5 (MODE 5): the fields' u pointers travel in P.v, everything else in Q

@@ -190,6 +190,29 @@ __device__ __forceinline__ void grad_issue_j(const GradFields& P, int64_t E, int
 __device__ unsigned long long fe_dbg_clock[2];
 __device__ unsigned long long fe_dbg_stamps[4096][4];
 __device__ unsigned long long fe_dbg_phase[4096][4];   // prologue: operator landed, barrier passed, fragments built, second barrier passed
+// per wave and per tile (the first four): 100 MHz stamps {loads landed, matrix work issued, stores issued, -} (grad);
+// {loads landed, B fragments built and next loads issued, matrix work issued, stores issued} (div, kDbg & 128).  Kept in 128 bytes
+// of LDS per wave behind the kernel's own (an LDS write counts on lgkmcnt, which the compiler tracks; a global store per stamp
+// would count on vmcnt and break the kernels' counted waits) and copied out when the wave ends.
+__device__ unsigned long long fe_dbg_tile[4096][16];
+constexpr int kDbgTileLdsBytes = 4 * 128;
+#define FE_TILE_STAMP(ENABLED, LDS_END, WAVE, LANE, IT, K)                                                              \
+    do {                                                                                                                 \
+        if ((ENABLED) && (IT) < 4) {                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                                           \
+            if ((LANE) == 0) reinterpret_cast<unsigned long long*>(LDS_END)[(WAVE) * 16 + (IT) * 4 + (K)] = now_;        \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }                                                                                                                \
+    } while (0)
+#define FE_TILE_STAMPS_OUT(ENABLED, LDS_END, WAVE, LANE, GLOBAL_WAVE)                                                    \
+    do {                                                                                                                 \
+        if ((ENABLED) && (GLOBAL_WAVE) < 4096 && (LANE) < 16)                                                            \
+            fe::fe_dbg_tile[GLOBAL_WAVE][LANE] = reinterpret_cast<unsigned long long*>(LDS_END)[(WAVE) * 16 + (LANE)];   \
+    } while (0)
+#else
+#define FE_TILE_STAMP(ENABLED, LDS_END, WAVE, LANE, IT, K) do {} while (0)
+#define FE_TILE_STAMPS_OUT(ENABLED, LDS_END, WAVE, LANE, GLOBAL_WAVE) do {} while (0)
 #endif
 
 // kDbg: experiment flags, 0 in the product build (tools/fe_check.cpp "ab" mode uses the others
@@ -336,8 +359,13 @@ __device__ __forceinline__ void grad3d_mfma_body(
     }
 
 
+    int dbg_it = 0;   // (experiments build: units done by this wave, for the per-tile stamps)
+#ifdef FE_EXPERIMENTS
+    if ((kDbg & 32) && lane < 16) reinterpret_cast<unsigned long long*>(smem + G::LDS_BYTES)[wave * 16 + lane] = 0;
+#endif
     // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
     auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt) {
+        FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
         double* out_x[3];
         out_x[0] = grad_plane_out(P, fk, 0);
         out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
@@ -369,6 +397,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
             }
 
+            FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the matrix work is issued
             // ---- stage 2 + transposed store, plane by plane
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
@@ -416,12 +445,15 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 wave_lds_fence();
             }
         }
+        FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the stores are issued
+        ++dbg_it;
     };
 
 #ifdef FE_EXPERIMENTS
     unsigned long long c0 = 0, r0 = 0;
     if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     auto write_stamps = [&](int tiles_done) {
+        FE_TILE_STAMPS_OUT(kDbg & 32, smem + G::LDS_BYTES, wave, lane, bid * G::WAVES + wave);
         if (!((kDbg & 32) && lane == 0)) return;
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         const int w = bid * G::WAVES + wave;

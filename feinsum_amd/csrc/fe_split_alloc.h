@@ -139,6 +139,9 @@ class SplitPool {
         if (const char* thr = getenv("FEINSUM_SPLIT_OTHER_ABOVE_GBPS")) other_above_gbps_ = atof(thr);
         if (const char* gib = getenv("FEINSUM_SPLIT_SEARCH_GIB")) search_budget_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
         if (const char* ms = getenv("FEINSUM_SPLIT_SEARCH_MS")) search_ms_budget_ = atof(ms);
+        // several ranks of one job on this device (rehearsals; LOCAL_WORLD_SIZE ranks normally have a device each): every
+        // pool may skip through its share of the free memory only
+        if (const char* sh = getenv("FEINSUM_SPLIT_SHARE")) share_ = std::max(1, atoi(sh));
         if (const char* gib = getenv("FEINSUM_SPLIT_VA_GIB")) va_cap_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
         // the anchor of class 0: ONE handle of 256 MiB (a single block of the driver's allocator, hence of one class --
         // a group of 32 small handles may straddle two runs, and an impure anchor makes every later reading ambiguous:
@@ -260,11 +263,11 @@ class SplitPool {
         return snprintf(buf, n,
                         "{\"ready\": %s, \"classes\": %zu, \"free_pieces\": %s, \"pooled_bytes\": %zu, \"live_bytes\": %zu, "
                         "\"live_arrays\": %zu, \"pieces_created\": %zu, \"groups_probed\": %zu, \"probes\": %zu, \"spacer_bytes_peak\": %zu, "
-                        "\"spacers_created\": %zu, \"spacer_ms\": %.1f, \"probe_ms\": %.1f, \"groups_discarded\": %zu, \"unsplit_arrays\": %zu, \"setup_ms\": %.3f, \"alloc_ms_total\": %.3f, "
+                        "\"spacers_created\": %zu, \"spacer_ms\": %.1f, \"probe_ms\": %.1f, \"search_ms\": %.1f, \"search_ms_budget\": %.0f, \"release_ms\": %.1f, \"groups_discarded\": %zu, \"unsplit_arrays\": %zu, \"setup_ms\": %.3f, \"alloc_ms_total\": %.3f, "
                         "\"same_class_below_gbps\": %.0f, \"walk_gave_up\": %s, \"piece_mib\": %zu, \"group_mib\": %zu, "
                         "\"address_space_reserved\": %zu, \"address_space_cap\": %zu, \"last_probes_gbps\": \"%s\"}",
                         ready_ ? "true" : "false", free_.size(), fr.c_str(), pooled * kSplitPiece, live_bytes_, live_.size(),
-                        pieces_created_, groups_probed_, probes_, spacer_bytes_peak_, spacers_created_, spacer_ms_, probe_ms_, groups_discarded_, unsplit_arrays_, setup_ms_,
+                        pieces_created_, groups_probed_, probes_, spacer_bytes_peak_, spacers_created_, spacer_ms_, probe_ms_, search_ms_, search_ms_budget_, release_ms_, groups_discarded_, unsplit_arrays_, setup_ms_,
                         alloc_ms_total_, same_below_gbps_, walk_gave_up_ ? "true" : "false", kSplitPiece / kSplitMiB,
                         kSplitGroupBytes / kSplitMiB, va_reserved_, va_cap_, last_probes_.c_str());
     }
@@ -305,10 +308,18 @@ class SplitPool {
     std::unordered_map<char*, SplitArray> live_;
     double same_below_gbps_ = kSplitSameBelowGBps, other_above_gbps_ = kSplitOtherAboveGBps, setup_ms_ = 0, alloc_ms_total_ = 0;
     double spacer_ms_ = 0, probe_ms_ = 0;
+    double search_ms_ = 0;    // wall clock of all searches of this pool: from a search's first spacer to the end of its acquire(),
+                              // the release of what was skipped included -- what search_ms_budget_ bounds IN TOTAL
+    double release_ms_ = 0;   // of that: handing the skipped memory back to the driver
+    int share_ = 1;           // pools (processes) searching this device at the same time ($FEINSUM_SPLIT_SHARE)
     size_t search_budget_ = 96ull << 30;   // how far a search for another class may skip ahead ($FEINSUM_SPLIT_SEARCH_GIB)
     size_t groups_discarded_ = 0;
     size_t va_cap_ = 16ull << 40;          // reserved address space this pool may reach ($FEINSUM_SPLIT_VA_GIB)
-    double search_ms_budget_ = 4000.0;     // ... and how long the skipping itself may take ($FEINSUM_SPLIT_SEARCH_MS)
+    double search_ms_budget_ = 4000.0;     // ... and how long ALL searches of this pool may take, wall clock, spacer creation, the
+                                           // groups obtained and probed on the way and the release of the spacers included
+                                           // ($FEINSUM_SPLIT_SEARCH_MS).  Round 4 bounded only the spacer creation of ONE search: with
+                                           // four ranks searching one device at once a "2.5 s" search took 10 s, 7 of them outside
+                                           // the clock (profiles/r04/rehearse4_selfspawn4.json)
     std::vector<hipMemGenericAllocationHandle_t> discarded_;   // pieces of ambiguous groups: held while a search runs
     size_t pieces_created_ = 0, groups_probed_ = 0, probes_ = 0, spacer_bytes_peak_ = 0, spacers_created_ = 0, unsplit_arrays_ = 0;
     size_t live_bytes_ = 0, va_reserved_ = 0;
@@ -513,7 +524,9 @@ class SplitPool {
         // (and clear) the skipped memory, 15-80 ms per GiB (fe_split_stats: "spacer_ms"); on fresh devices the next run began
         // 1 ... 33 GiB ahead.  Budget: $FEINSUM_SPLIT_SEARCH_GIB (default 96: a superclass is 96 GB), at most what is free minus 12 GiB; a search
         // that found nothing is not repeated until fe_split_trim.
-        const size_t spacer_budget = (!walk_gave_up_ && free_mem > (16ull << 30)) ? std::min<size_t>(search_budget_, free_mem - (12ull << 30)) : 0;
+        const size_t free_share = free_mem / (size_t)share_;
+        const size_t spacer_budget = (!walk_gave_up_ && search_ms_ < search_ms_budget_ && free_share > (16ull << 30))
+                                         ? std::min<size_t>(search_budget_, free_share - (12ull << 30)) : 0;
         auto pick = [&](int* a, int* b) {
             int c1 = -1, c2 = -1;   // the two fullest classes
             for (int c = 0; c < (int)free_.size(); ++c) {
@@ -528,8 +541,13 @@ class SplitPool {
         const size_t max_new = walk_gave_up_ ? 2 * need_groups + 2 : 8 * need_groups + 64;   // groups obtained in this call at most
         size_t made = 0, run = 0;
         int rc = FE_OK;
-        const double spacer_ms_at_start = spacer_ms_;
+        // the clock of this search starts with its first spacer; half of what is left of the pool's budget is kept for giving
+        // the skipped memory back (measured with four pools on one device: as long again as obtaining it)
+        double t_search = -1.0;
+        const double search_left = search_ms_budget_ - search_ms_;
+        auto search_elapsed = [&] { return t_search < 0 ? 0.0 : split_now_ms() - t_search; };
         while (!pick(ca, cb) && made < max_new) {
+            if (t_search >= 0 && search_elapsed() > 0.5 * search_left) break;   // out of time: the groups obtained while skipping count too
             // the driver hands out long runs of one class: with enough of the current run's class in the pool, skip
             // ahead with an unmapped spacer (doubling, 1 ... 16 GiB) before the next group
             // (not before the pool holds 512 MiB of the current run's class, or what fe_split_reserve announced: the arrays of a
@@ -538,9 +556,10 @@ class SplitPool {
             // walk had collected: profiles/r03/bench_pipeline_walk_gave_up.json)
             if (free_[last_cls_].size() >= std::max(need, collect) && run >= 3) {
                 if (spacer_bytes >= spacer_budget) break;   // nowhere left to search
-                if (spacer_ms_ - spacer_ms_at_start > search_ms_budget_) break;   // the driver is clearing what is skipped: enough
+                if (t_search < 0) t_search = split_now_ms();
                 if (spacer_bytes + next_spacer > spacer_budget) next_spacer = (spacer_budget - spacer_bytes) / kSplitGran * kSplitGran;
                 if (next_spacer == 0) break;
+                if (search_left < 3000.0) next_spacer = std::min<size_t>(next_spacer, 2048 * kSplitMiB);   // (a step is 15-80 ms per GiB: keep the clock's grain fine)
                 // The skipped memory is taken in handles of 32 MiB, not in one large handle: the driver's buddy allocator
                 // serves a request from the SMALLEST free block that fits, so 4 MiB pieces keep coming from the block it is
                 // currently splitting whatever large blocks are taken elsewhere (one 1 ... 16 GiB spacer per step left the
@@ -550,11 +569,14 @@ class SplitPool {
                 // mixed memory -- split_alloc_check_v9_*.txt; with 32 MiB at most 28 MiB: less than one group.)
                 const double t_sp = split_now_ms();
                 bool ok = true;
-                for (size_t done = 0; done < next_spacer && ok; done += kSplitSpacerUnit) {
+                size_t done = 0;
+                for (; done < next_spacer && ok; done += kSplitSpacerUnit) {
+                    if ((done & (1024 * kSplitMiB - 1)) == 0 && search_elapsed() > 0.5 * search_left) break;   // (checked every GiB)
                     hipMemGenericAllocationHandle_t sp;
                     ok = hipMemCreate(&sp, kSplitSpacerUnit, &prop_, 0) == hipSuccess;
                     if (ok) spacers.push_back(sp);
                 }
+                next_spacer = done;
                 spacer_ms_ += split_now_ms() - t_sp;
                 if (!ok) {
                     (void)hipGetLastError();
@@ -574,9 +596,14 @@ class SplitPool {
             if (got != before) next_spacer = first_spacer;
         }
         spacer_bytes_peak_ = std::max(spacer_bytes_peak_, spacer_bytes);
+        const double t_rel = split_now_ms();
         for (auto& sp : spacers) (void)hipMemRelease(sp);
         for (auto& h : discarded_) (void)hipMemRelease(h);
         discarded_.clear();
+        if (t_search >= 0) {
+            release_ms_ += split_now_ms() - t_rel;
+            search_ms_ += split_now_ms() - t_search;
+        }
         for (auto& list : free_)   // what a long search collected of the class it did not need goes back to the driver
             while (list.size() > std::max(max_pooled_pieces_ / 2, std::max(need, reserve_pieces_))) {
                 (void)hipMemRelease(list.back().handle);

@@ -32,11 +32,17 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Counts the FE_EHIP returns of this process: after a HIP error a launch may not have run to completion, and a dynamic launch
+// that stopped half way leaves tickets in its counter group (later launches through that group would skip tiles).  The first
+// dynamic launch of every stream after such a return verifies its group once (tail_slot below).
+std::atomic<unsigned> g_hip_error_epoch{0};
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    if (code == FE_EHIP) g_hip_error_epoch.fetch_add(1, std::memory_order_relaxed);
     return code;
 }
 
@@ -167,6 +173,16 @@ unsigned generic_grid(int64_t E, int Np) { return (unsigned)((E * Np + 255) / 25
 //  * fe_stream_retired() returns a destroyed stream's group; fe_tail_check() verifies the zero-between-launches invariant
 //    on an idle device (and repairs it), FEINSUM_TAIL_CHECK=1 does so before every dynamic launch (debugging aid: it
 //    synchronises the stream).
+// Round 5 closes three edges of that scheme:
+//  * ONE EXECUTABLE PER CAPTURE.  The group pointer is baked into the graph NODE: every executable instantiated from one
+//    captured graph uses the same counters, and HIP orders only the launches of one executable.  Two executables of one
+//    capture must not run at the same time (include/feinsum_hip.h says so; BoundOperator.capture() instantiates one).
+//  * captured groups come back: the groups a capture took are recorded under the capture's id (fe_capture_id), and
+//    fe_graph_retired(id) returns them once the caller has destroyed the graph -- an application that re-captures every
+//    step no longer runs out of groups after kTailMaxGroups captures and falls back to the static walk for good;
+//    fe_tail_stats reports `exhausted` and `static_fallbacks` so that the fallback is visible;
+//  * a failed chunk allocation is retried (not latched), and after any FE_EHIP return of the process the first dynamic
+//    launch of every stream verifies (and repairs) its group once -- the checked mode is no longer opt-in where it matters.
 constexpr int kTailSetsPerGroup = 4;
 constexpr int kTailChunkGroups = 16;                     // 8.9 MB per chunk
 constexpr int kTailMaxGroups = 256;                      // per device
@@ -174,15 +190,24 @@ constexpr size_t kTailGroupWords = (size_t)kTailSetsPerGroup * fe::kTailWords;
 struct TailPool {
     std::mutex lock;
     std::unordered_map<uintptr_t, unsigned*> by_stream;   // eager launches
+    std::unordered_map<uintptr_t, unsigned> verified_at;  // per stream: the FE_EHIP epoch its group was last verified at
+    std::unordered_map<unsigned long long, std::vector<unsigned*>> by_capture;   // capture id -> the groups its nodes own
     std::vector<unsigned*> spare;                          // zeroed groups nobody owns
     std::vector<unsigned*> chunks;                         // every allocation (fe_tail_check walks them)
     int groups = 0, captured = 0;
-    bool failed = false;
+    long long exhausted = 0;          // launches that found no group (all kTailMaxGroups owned, or none spare during capture)
+    long long static_fallbacks = 0;   // launches that wanted tickets and walked statically (exhausted, failed allocation, HIP errors)
+    long long grow_failures = 0;      // chunk allocations that failed (retried by later launches)
+    long long verified_after_error = 0, repaired_after_error = 0;
+    int failed_recently = 0;          // launches to wait before the next allocation attempt
     hipStream_t zero_stream = nullptr;
     // a fresh chunk: zeroed through a stream of our own and waited for, so that whoever takes a group later -- on any
     // stream -- finds zeros without being ordered behind anything
     bool grow() {
-        if (failed || groups + kTailChunkGroups > kTailMaxGroups) return false;
+        if (groups + kTailChunkGroups > kTailMaxGroups) return false;
+        // a failed allocation (say during another thread's global-mode capture) is not final: the launches walk statically
+        // meanwhile and the 64th of them tries again
+        if (failed_recently > 0) { --failed_recently; return false; }
         unsigned* p = nullptr;
         const size_t bytes = (size_t)kTailChunkGroups * kTailGroupWords * sizeof(unsigned);
         bool ok = zero_stream || hipStreamCreateWithFlags(&zero_stream, hipStreamNonBlocking) == hipSuccess;
@@ -191,7 +216,8 @@ struct TailPool {
         if (!ok) {
             (void)hipGetLastError();
             if (p) (void)hipFree(p);
-            failed = true;
+            ++grow_failures;
+            failed_recently = 64;
             return false;
         }
         chunks.push_back(p);
@@ -228,34 +254,63 @@ unsigned* tail_slot(hipStream_t s, int sets = 1) {
     int dev = 0;
     if (sets < 1 || sets > kTailSetsPerGroup) return nullptr;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    TailPool& pool = g_tail[dev];
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    unsigned long long capture_id = 0;
+    if (hipStreamGetCaptureInfo(s, &st, &capture_id) != hipSuccess) {
         (void)hipGetLastError();
+        std::lock_guard<std::mutex> guard(pool.lock);
+        ++pool.static_fallbacks;
         return nullptr;
     }
-    TailPool& pool = g_tail[dev];
     std::lock_guard<std::mutex> guard(pool.lock);
-    if (st != hipStreamCaptureStatusNone) {   // a graph node: a group of its own, never handed out again
-        if (pool.spare.empty()) return nullptr;
+    if (st != hipStreamCaptureStatusNone) {   // a graph node: a group of its own until fe_graph_retired(capture id)
+        if (pool.spare.empty()) {              // (no allocation during capture)
+            ++pool.exhausted;
+            ++pool.static_fallbacks;
+            return nullptr;
+        }
         unsigned* g = pool.spare.back();
         pool.spare.pop_back();
         ++pool.captured;
+        pool.by_capture[capture_id].push_back(g);
         return g;
     }
     const uintptr_t key = tail_stream_key(s);
     auto it = pool.by_stream.find(key);
     if (it == pool.by_stream.end()) {
         // keep a chunk's worth of spares behind the eager streams, so that a later capture finds some
-        if (pool.spare.size() <= 1 && !pool.grow() && pool.spare.empty()) return nullptr;
+        if (pool.spare.size() <= 1 && !pool.grow() && pool.spare.empty()) {
+            if (pool.groups + kTailChunkGroups > kTailMaxGroups) ++pool.exhausted;
+            ++pool.static_fallbacks;
+            return nullptr;
+        }
         unsigned* g = pool.spare.back();
         pool.spare.pop_back();
         it = pool.by_stream.emplace(key, g).first;
+        pool.verified_at[key] = g_hip_error_epoch.load(std::memory_order_relaxed);   // fresh from the spares: zero
     }
-    if (g_tail_check.load(std::memory_order_relaxed)) {   // debugging aid: the group must be zero once the stream is idle
+    // after any FE_EHIP return of the process a launch may have stopped half way: the first dynamic launch of every stream
+    // behind it verifies its group once (it waits for the stream: rare, and only after an error); FEINSUM_TAIL_CHECK=1 does
+    // so before EVERY dynamic launch (debugging aid)
+    const unsigned epoch = g_hip_error_epoch.load(std::memory_order_relaxed);
+    unsigned& seen = pool.verified_at[key];
+    const bool after_error = seen != epoch;
+    if (after_error || g_tail_check.load(std::memory_order_relaxed)) {
         long long dirty = 0;
-        if (hipStreamSynchronize(s) != hipSuccess || tail_group_dirty(it->second, true, &dirty) != FE_OK || dirty) {
-            fprintf(stderr, "feinsum_hip: ticket counters of stream %p held %lld non-zero words before a launch (repaired)\n",
-                    (void*)s, dirty);
+        const bool ok = hipStreamSynchronize(s) == hipSuccess && tail_group_dirty(it->second, true, &dirty) == FE_OK;
+        if (!ok) (void)hipGetLastError();
+        if (after_error) {
+            ++pool.verified_after_error;
+            if (dirty) ++pool.repaired_after_error;
+            if (ok) seen = epoch;
+        }
+        if (!ok || dirty)
+            fprintf(stderr, "feinsum_hip: ticket counters of stream %p held %lld non-zero words before a launch (%s)\n",
+                    (void*)s, dirty, ok ? "repaired" : "could not be verified: static walk");
+        if (!ok) {
+            ++pool.static_fallbacks;
+            return nullptr;
         }
     }
     return it->second;
@@ -309,22 +364,11 @@ int write_through_flag(int64_t output_bytes) {
 
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
-#ifndef FE_GRID_MODE
-#define FE_GRID_MODE 0
-#endif
+// (a per-wave-equal grid -- every wave the same number of tiles, on fewer waves -- was measured in round 3 and is slower at
+// every size: profiles/r03/balanced_grid_ab.txt)
 unsigned persistent_grid(int64_t nTiles, int wavesPerBlock) {
-    int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
+    const int64_t blocks = (nTiles + wavesPerBlock - 1) / wavesPerBlock;
     const int64_t cap = (8 / wavesPerBlock) * (int64_t)device_cu_count();   // 8 waves per CU
-#if FE_GRID_MODE == 1
-    // experiment: every wave walks the same number of tiles k = ceil(nTiles / resident waves), on
-    // ceil(nTiles / k) waves -- no last round on a fraction of the machine (E = 1e5: 1563 waves x 4 tiles instead of
-    // 106 x 4 + 1942 x 3)
-    if (blocks > cap) {
-        const int64_t k = (nTiles + cap * wavesPerBlock - 1) / (cap * wavesPerBlock);
-        const int64_t waves = (nTiles + k - 1) / k;
-        blocks = (waves + wavesPerBlock - 1) / wavesPerBlock;
-    }
-#endif
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
@@ -456,6 +500,32 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
     return FE_OK;
 }
 
+// EXPERIMENT (round 5): p = 4 grad / div on the eight-wave kernels (A in LDS), two blocks per CU = four waves per SIMD
+// (FEINSUM_WIDE_BLOCKS / fe_set_wide_blocks: 0 never, 1 always, N > 1: launches of at most N tiles)
+std::atomic<long long> g_wide_blocks{[] { const char* e = getenv("FEINSUM_WIDE_BLOCKS"); return e ? atoll(e) : 0ll; }()};
+bool wide_blocks_wanted(int64_t nTiles) {
+    const long long w = g_wide_blocks.load(std::memory_order_relaxed);
+    return w == 1 || (w > 1 && nTiles <= w);
+}
+template <int NP, int MODE>
+int launch_wide(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT, hipStream_t s,
+                int64_t* e_done) {
+    using G = fe::DivGeom<NP, 1, MODE, 3, true, true>;
+    static_assert(2 * G::LDS_BYTES <= 160 * 1024, "two eight-wave blocks per CU");
+    const int64_t nTiles = E / G::TEL;
+    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
+    if (nTiles == 0) return FE_OK;
+    opT |= temporal_flag((9 + (MODE == 0 ? 3 : 1) * (int64_t)nb * NP) * E * 8);
+    static PerDeviceOnce once;
+    if (int rc = configured(once, fe::wide_w8_kernel<NP, MODE>, MODE == 4 ? "grad p4, eight-wave blocks x 2 per CU" : "div p4, eight-wave blocks x 2 per CU",
+                            G::LDS_BYTES, G::THREADS, 2))
+        return rc;
+    const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = 2 * (int64_t)device_cu_count();
+    hipLaunchKernelGGL((fe::wide_w8_kernel<NP, MODE>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(G::THREADS), G::LDS_BYTES, s, J, D, P,
+                       nb, E, nTiles, opT);
+    return FE_OK;
+}
+
 // ---- the LDS-tiled VALU kernel (fe_tiled.h): any shape whose operator fits in LDS
 constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
 
@@ -545,11 +615,11 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 4>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 16>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 20>, "experiment", G::LDS_BYTES, 256, 1);
-            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 128>, "experiment", G::LDS_BYTES, 256, 1);
-            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, "grad (experiments build)", G::LDS_BYTES, 256, 2);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0, true, true>, "grad prepared (experiments build)", G::LDS_BYTES, 256, 2);
         }
@@ -579,7 +649,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
         case 20: FE_GRAD_CASE(20); break;   // both
         case 32:
             if (gsec) {
-                hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32, true, true>), g, b, G::LDS_BYTES, s, P, D, gsec, nb, nx,
+                hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32, true, true>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, P, D, gsec, nb, nx,
                                    E, nTiles, opT);
                 break;
             }
@@ -588,12 +658,13 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                 unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                 if (tail) {
                     static PerDeviceOnce once_stamps;
-                    once_stamps.run([] { return configure_kernel(fe::grad3d_mfma_tail_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1); });
-                    hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 32>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
+                    once_stamps.run([] { return configure_kernel(fe::grad3d_mfma_tail_kernel<NP, M, 32>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1); });
+                    hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 32>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, P, D, nb, E, nTiles, opT, tail, t_static);
                     break;
                 }
             }
-            FE_GRAD_CASE(32);
+            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (as the product's static walk)
+            hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, P, D, nullptr, nb, nx, E, nTiles, opT);
             break;
         case 64: FE_GRAD_CASE(64); break;
         case 96: FE_GRAD_CASE(96); break;
@@ -665,6 +736,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 8>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::div3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::div3d_mfma_kernel<NP, M, 128>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
         }
         return FE_OK;
     });
@@ -681,6 +753,9 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 8: FE_DIV_CASE(8); break;
         case 32: FE_DIV_CASE(32); break;   // one u plane loaded instead of three (timing only)
         case 64: FE_DIV_CASE(64); break;   // the tile after next touched line by line (L2 prefetch)
+        case 128:                          // per-wave, per-tile time stamps (fe_dbg_tile)
+            hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 128>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
+            break;
 #endif
         default:
             if (prep) {
@@ -905,7 +980,9 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_grad<35, 1>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 35:
+                if (Jfull && nb == 1 && !prep && dbg == 0 && wide_blocks_wanted(E / 16)) { rc = launch_wide<35, 4>(Jfull, D, Pt, nb, E, opT, s, &e_done); break; }
+                rc = launch_grad<35, 1>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             case 20: rc = launch_grad<20, 2>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             case 10: rc = launch_grad<10, 3>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             default: rc = launch_grad<4, 5>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
@@ -1491,11 +1568,13 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
     }
     int64_t e_done = 0;
     if (path == kPathMfma) {
-        const int dbg = variant >= 1000 ? (variant - 1000) & 127 : 0;   // experiment builds only
+        const int dbg = variant >= 1000 ? (variant - 1000) & 255 : 0;   // experiment builds only
         int rc = FE_OK;
         const int opf = opT | (split_walk ? fe::kDivWalkSplit : 0);
         switch (Np) {   // wave tile = 16 M elements
-            case 35: rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
+            case 35:
+                if (b == 1 && !prep && dbg == 0 && !split_walk && wide_blocks_wanted(E / 16)) { rc = launch_wide<35, 0>(J, D, P, b, E, opT, s, &e_done); break; }
+                rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             case 20: rc = launch_div<20, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             case 10: rc = launch_div<10, 3>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             default: rc = launch_div<4, 5>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
@@ -2007,6 +2086,11 @@ int fe_dbg_read_phase(unsigned long long* out, int n_waves) {
     FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_phase), (size_t)n_waves * 32));
     return FE_OK;
 }
+int fe_dbg_read_tiles(unsigned long long* out, int n_waves) {
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_tile), (size_t)n_waves * 128));
+    return FE_OK;
+}
 int fe_dbg_read_stamps(unsigned long long* out, int n_waves) {
     FE_HIP_CHECK(hipDeviceSynchronize());
     FE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(fe::fe_dbg_stamps), (size_t)n_waves * 32));
@@ -2027,6 +2111,10 @@ int fe_set_write_through_mib(int32_t mib) {
     return (int)(g_write_through_output_bytes.exchange(mib < 0 ? 0 : (long long)mib << 20) >> 20);
 }
 
+int fe_set_wide_blocks(int64_t tiles) {
+    return (int)g_wide_blocks.exchange(tiles < 0 ? 0 : tiles);
+}
+
 int fe_set_cu_limit(int32_t cus) {
     return g_cu_limit.exchange(cus < 0 ? 0 : cus);
 }
@@ -2040,8 +2128,47 @@ int fe_stream_retired(void* stream) {
     auto it = pool.by_stream.find(tail_stream_key(static_cast<hipStream_t>(stream)));
     if (it == pool.by_stream.end()) return 0;
     pool.spare.push_back(it->second);   // zero, like every group between launches
+    pool.verified_at.erase(it->first);
     pool.by_stream.erase(it);
     return 1;
+}
+
+int fe_capture_id(void* stream, uint64_t* id) {
+    if (!id) return fail(FE_EINVAL, "fe_capture_id: null result pointer");
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    FE_HIP_CHECK(hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &st, &cid));
+    *id = st == hipStreamCaptureStatusNone ? 0 : (uint64_t)cid;
+    return FE_OK;
+}
+
+int fe_graph_retired(uint64_t capture_id) {
+    int dev = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FE_EINVAL, "fe_graph_retired: device %d", dev);
+    TailPool& pool = g_tail[dev];
+    std::lock_guard<std::mutex> guard(pool.lock);
+    auto it = pool.by_capture.find((unsigned long long)capture_id);
+    if (it == pool.by_capture.end()) return 0;
+    const int n = (int)it->second.size();
+    for (unsigned* g : it->second) pool.spare.push_back(g);   // zero, like every group between launches
+    pool.captured -= n;
+    pool.by_capture.erase(it);
+    return n;
+}
+
+int fe_tail_stats(int64_t* out, int32_t n) {
+    if (!out || n < 1) return fail(FE_EINVAL, "fe_tail_stats: bad arguments");
+    int dev = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FE_EINVAL, "fe_tail_stats: device %d", dev);
+    TailPool& pool = g_tail[dev];
+    std::lock_guard<std::mutex> guard(pool.lock);
+    const int64_t v[FE_TAIL_STATS] = {pool.groups, (int64_t)pool.by_stream.size(), pool.captured, (int64_t)pool.spare.size(), pool.exhausted,
+                                      pool.static_fallbacks, pool.grow_failures, pool.verified_after_error, pool.repaired_after_error,
+                                      (int64_t)pool.by_capture.size(), kTailMaxGroups, (int64_t)g_hip_error_epoch.load()};
+    for (int k = 0; k < n && k < FE_TAIL_STATS; ++k) out[k] = v[k];
+    return n < FE_TAIL_STATS ? n : FE_TAIL_STATS;
 }
 
 int fe_tail_plant(void* stream, uint32_t value) {

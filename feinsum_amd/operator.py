@@ -139,6 +139,7 @@ class BoundOperator:
     def __init__(self, queue: Any, launches: List[Any], outputs: List[Mapping[str, Any]]) -> None:
         self.queue, self.launches, self.outputs = queue, launches, outputs
         self._graph = None
+        self._capture_id = 0
 
     @property
     def entry_points(self) -> Tuple[str, ...]:
@@ -170,17 +171,48 @@ class BoundOperator:
         synchronise, so they can be captured); :meth:`replay` then enqueues it with a single call.
         Pays off for operators of several launches on small element counts, where the host-side
         cost of the launches is comparable to the kernels.  The bound arrays stay the operands:
-        update them in place between replays."""
+        update them in place between replays.
+
+        ONE executable per capture: a captured launch's ticket counters belong to the graph node (include/feinsum_hip.h), so
+        this object holds the one executable of its capture; capturing again first gives the previous graph's counter groups
+        back (:meth:`release_graph`), and so does deleting the operator."""
         import torch
 
+        from feinsum_amd import _hip
+
+        self.release_graph()
         with torch.cuda.device(self.queue.torch_device):
             self.launch()                       # warm-up outside capture: kernel attributes
             self.queue.finish()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=torch.cuda.Stream(self.queue.torch_device)):
-                self.launch(int(torch.cuda.current_stream().cuda_stream))
+                s = int(torch.cuda.current_stream().cuda_stream)
+                self._capture_id = _hip.capture_id(s)
+                self.launch(s)
         self._graph = graph
         return self
+
+    def release_graph(self) -> int:
+        """Destroy the captured graph (after waiting for its replays) and hand its launches' ticket-counter groups back to the
+        library (``fe_graph_retired``); returns the number of groups returned.  Called by :meth:`capture` and on deletion."""
+        if self._graph is None:
+            return 0
+        import torch
+
+        from feinsum_amd import _hip
+
+        with torch.cuda.device(self.queue.torch_device):
+            torch.cuda.synchronize()
+            self._graph.reset()
+            self._graph = None
+            cid, self._capture_id = self._capture_id, 0
+            return _hip.graph_retired(cid) if cid else 0
+
+    def __del__(self) -> None:
+        try:
+            self.release_graph()
+        except Exception:       # noqa: BLE001  (interpreter shutdown: the library or torch may be gone)
+            pass
 
     def replay(self) -> None:
         """Enqueue the captured evaluation on the current stream."""

@@ -192,14 +192,16 @@ def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict
     # shard per field) must not leave the others waiting inside the collective -- every rank learns of it through one
     # all-reduce of a flag and all of them skip the exchange
     staged, why = [], ""
-    try:
+    flag = _agree_flag(fields[0][0].device if fields else None)   # allocated BEFORE the staging attempt: a rank that has just run out
+    try:                                                           # of memory must still be able to say so
+
         for local, axis in fields:
             moved = _comm_tensor(local.movedim(axis, 0).contiguous())
             staged.append((moved, torch.empty((world,) + tuple(moved.shape), dtype=moved.dtype, device=moved.device)))
     except (RuntimeError, MemoryError) as exc:      # torch.cuda.OutOfMemoryError is a RuntimeError
         why = f"{type(exc).__name__}: {exc}"[:200]
-        staged = []
-    if not all_agree(not why, fields[0][0].device if fields else None):
+        staged = []          # (released before the all-reduce below)
+    if not all_agree(not why, flag=flag):
         return {"skipped": "a rank could not stage its receive buffers" + (f" (this rank: {why})" if why else " (another rank)"),
                 "world_size": world}
     barrier()
@@ -217,15 +219,26 @@ def allgather_fields_timed(fields: Sequence[Tuple[Any, int]], sync: Any) -> dict
             "sums": [float(full.sum().item()) for _, full in staged], "world_size": world}
 
 
-def all_agree(ok: bool, device: Any = None) -> bool:
-    """True when *ok* holds on EVERY rank (one all-reduce of a flag; every rank must call it)."""
+def _agree_flag(device: Any = None) -> Any:
+    """The one-element tensor :func:`all_agree` reduces (on the device for RCCL, on the host for gloo)."""
     import torch
     import torch.distributed as dist
 
     if not in_group():
-        return bool(ok)
+        return None
     on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
-    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=on)
+    return torch.ones(1, dtype=torch.float64, device=on)
+
+
+def all_agree(ok: bool, device: Any = None, flag: Any = None) -> bool:
+    """True when *ok* holds on EVERY rank (one all-reduce of a flag; every rank must call it).  *flag*: a tensor from
+    :func:`_agree_flag` made ahead of time -- a rank whose *ok* is "I ran out of memory" cannot be asked to allocate one."""
+    import torch.distributed as dist
+
+    if not in_group():
+        return bool(ok)
+    t = flag if flag is not None else _agree_flag(device)
+    t.fill_(1.0 if ok else 0.0)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item() > 0.5)
 
@@ -240,6 +253,20 @@ def barrier() -> None:
             dist.barrier(device_ids=[torch.cuda.current_device()])   # this rank's own GPU
         else:
             dist.barrier()
+
+
+def gather_rows(values: Sequence[float], device: Any = None) -> List[List[float]]:
+    """Every rank's row of floats (equal lengths), in rank order; one all-gather of a small float64 tensor."""
+    import torch
+    import torch.distributed as dist
+
+    if not in_group():
+        return [[float(v) for v in values]]
+    on = device if (device is not None and dist.get_backend() != "gloo") else "cpu"
+    send = torch.tensor([float(v) for v in values], dtype=torch.float64, device=on)
+    rows = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, send)
+    return [[float(x) for x in r.tolist()] for r in rows]
 
 
 def max_over_ranks(value: float, device: Any = None) -> float:

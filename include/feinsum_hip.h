@@ -387,11 +387,13 @@ int fe_set_tail_rounds(int32_t rounds);
 /* Who owns ticket counters (the re-entrancy contract of SURVEY 8(b): no launch shares mutable state with a launch that can
  * run beside it).  A launch's counters are zero before and after it, so only launches the device serialises share them:
  * an eager launch uses the counter group of its STREAM (the per-thread default stream: of its thread), a launch recorded
- * during stream capture gets a group of its own for the life of the process (the graph may be replayed beside anything).
+ * during stream capture gets a group of its own until fe_graph_retired (the graph may be replayed beside anything).
  * Any number of streams, driven from any number of host threads, may launch at the same time.  Groups (0.56 MB) are
  * allocated on demand outside capture, at most 256 per device; a launch that finds none walks statically (same results).
  *   fe_stream_retired  a stream was destroyed (its launches have completed): its group may serve another stream.
- *                      Returns 1 if the stream had one, 0 if not.  Optional -- without it the group stays with the handle.
+ *                      Returns 1 if the stream had one, 0 if not.  Optional -- without it the group stays with the handle
+ *                      VALUE: call it before hipStreamDestroy of a stream with work still in flight, or a new stream that is
+ *                      given the same handle could run beside that work on the same counters.
  *   fe_tail_check      waits for the current device, then counts the non-zero words in all counter groups (there must be
  *                      none: a launch that did not run to completion would leave some, and later launches through that
  *                      group would skip tiles) and, with `repair`, zeroes them.  Also reports the groups allocated, the
@@ -401,6 +403,26 @@ int fe_set_tail_rounds(int32_t rounds);
  * The reference's executor is single-queue (src/feinsum/measure.py:163-165,243-251); no counterpart. */
 int fe_stream_retired(void* stream);
 int fe_tail_check(int32_t repair, int64_t* dirty_words, int32_t* groups, int32_t* streams, int32_t* captured);
+/* Launches recorded during stream capture (round 5):
+ *   ONE EXECUTABLE PER CAPTURE.  A captured launch's counter group is part of the graph NODE, so every executable
+ *   instantiated from one captured graph uses the same counters, and HIP orders only the launches of ONE executable against
+ *   each other: two executables of one capture must never run at the same time (capture again for a second executable).
+ *   fe_capture_id     *id = the id of the capture in progress on `stream` (hipStreamGetCaptureInfo), 0 when it is not capturing:
+ *                     ask between the begin and the end of the capture, keep it with the graph.
+ *   fe_graph_retired  the graph captured under `capture_id` and all its executables have been destroyed (their launches have
+ *                     completed): the groups its nodes owned may serve others.  Returns how many came back (0: unknown id).
+ *                     Without it a process that captures again and again runs out of groups after 256 captured launches and
+ *                     walks statically from then on (3-5 % slower, never wrong).
+ *   fe_tail_stats     out[0..n): groups allocated, streams owning one, groups owned by graph nodes, spare groups, `exhausted`
+ *                     (launches that found every group owned), `static_fallbacks` (launches that wanted tickets and walked
+ *                     statically for any reason), failed chunk allocations (retried later), groups verified / repaired after
+ *                     an FE_EHIP return, live captures, the cap (256), FE_EHIP returns so far.  Returns the number written.
+ * After ANY FE_EHIP return of the process the first dynamic launch of every stream waits for that stream once and verifies
+ * (repairs) its group: a launch that did not run to completion cannot leave tickets behind for later launches. */
+#define FE_TAIL_STATS 12
+int fe_capture_id(void* stream, uint64_t* id);
+int fe_graph_retired(uint64_t capture_id);
+int fe_tail_stats(int64_t* out, int32_t n);
 /* Test hook: waits for the device and writes `value` into one ticket counter of the group `stream` owns (FE_EINVAL if it
  * owns none) -- the state an interrupted launch would leave behind; tests/test_gpu_streams.py shows fe_tail_check finding
  * and repairing it. */
@@ -419,6 +441,11 @@ int fe_set_temporal_loads_mib(int32_t mib);
  * (default 128, also FEINSUM_WRITE_THROUGH_MIB; 0 = never): those store write-through (sc0 sc1), which leaves no dirty lines for
  * the end of the launch to write back (E = 1e5: 24.0 -> 23.3 us).  Returns the previous setting.  Results do not depend on it. */
 int fe_set_write_through_mib(int32_t mib);
+
+/* Short launches of p = 4 grad / div (one field) on the sixteen-waves-per-CU kernels (operator fragments in LDS, two
+ * eight-wave blocks per CU): launches of at most `tiles` 16-element tiles (0 = never, 1 = always; also FEINSUM_WIDE_BLOCKS).
+ * Returns the previous setting.  Results agree with the default kernels to rounding (another summation order of r). */
+int fe_set_wide_blocks(int64_t tiles);
 
 /* Size the persistent grids as if the device had `cus` compute units (0 = what the device reports; also
  * FEINSUM_CU_LIMIT).  MI355X partitions report 32 (CPX) or 64 (QPX) CUs: grids of fewer than 128 blocks walk statically

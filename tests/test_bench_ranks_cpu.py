@@ -49,7 +49,13 @@ def _worker(rank, world, port, elems_total, elems_per_gpu, tmpdir):
         time.sleep(0.02 * (rank + 1) * n)
         return 0.01 * (rank + 1) * n
 
-    wall_s, kernel_s = bench.timed_region(step_batch, 3, sync=lambda: None)
+    timed = bench.timed_region(step_batch, 3, sync=lambda: None)
+    wall_s, kernel_s = timed["wall"], timed["kernel"]
+    # the closing barrier is outside `wall`: rank 0 is done after 3 x 20 ms and only then waits for rank 1
+    assert timed["local_wall"] == pytest.approx(0.06 * (rank + 1), abs=0.03) and timed["local_kernel"] == pytest.approx(0.03 * (rank + 1))
+    assert timed["wall_barrier"] >= timed["wall"] >= timed["local_wall"]
+    per_rank = bench.gather_rank_reports({"elements": E, "kernel_ms": timed["local_kernel"] / 3 * 1e3, "wall_ms": timed["local_wall"] / 3 * 1e3,
+                                          "placement_mode": "split", "unsplit_arrays": rank, "allocator_ms": 10.0 * rank})
     total, red_ms, gather_ms = bench.exchange_results([torch.from_numpy(out)], sync=lambda: None)
     flops = float(f.count_ops(expr, long_dim_length=E))
     t = torch.tensor([flops], dtype=torch.float64)
@@ -64,7 +70,7 @@ def _worker(rank, world, port, elems_total, elems_per_gpu, tmpdir):
                                   bytes_step_rank0=8.0 * (149 * E + 3675) * 1e6, elems_rank0=E, elems_total=elems_total,
                                   variant="auto", device_name="cpu rehearsal", entry_points=("fe_grad",),
                                   extra={"result_reduction_ms": red_ms, "result_allgather_ms": gather_ms})
-        json.dump({"line": line, "total": total.tolist(), "wall_s": wall_s, "kernel_s": kernel_s},
+        json.dump({"line": line, "total": total.tolist(), "wall_s": wall_s, "kernel_s": kernel_s, "per_rank": per_rank},
                   open(os.path.join(tmpdir, "rank0.json"), "w"))
     dist.destroy_process_group()
 
@@ -105,6 +111,11 @@ def test_two_rank_bench_logic(tmp_path, elems_total, elems_per_gpu):
     assert line["roofline"]["achieved"] == pytest.approx(8.0 * (149 * e0 + 3675) * 1e6 / 0.02 * 1e-9, rel=1e-3)
     assert {"result_reduction_ms", "result_allgather_ms", "setup_launches", "ms_per_step"} <= set(line)
     assert line["roofline"]["traffic"] is None
+    # every rank's own figures reach rank 0: a slow rank (or one whose allocator search failed) is attributable
+    pr = rec["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and [r["unsplit_arrays"] for r in pr] == [0, 1]
+    assert pr[1]["kernel_ms"] == pytest.approx(20.0) and pr[0]["kernel_ms"] == pytest.approx(10.0)
+    assert pr[1]["wall_ms"] > pr[0]["wall_ms"] and pr[0]["placement_mode"] == "split"
 
 
 def test_committed_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
@@ -117,10 +128,12 @@ def test_committed_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     monkeypatch.setattr(bench, "kernel_source_sha", lambda: sha)
     rec = {"E": 1000, "source_sha": sha, "hbm_bytes_per_launch": 123.0, "kernel": "k"}
-    (prof / "traffic_grad.json").write_text(json.dumps(rec))
+    (prof / "traffic_grad_E1000.json").write_text(json.dumps(rec))        # (E = 1e6: traffic_grad.json; other sizes carry theirs)
     assert bench.committed_counters("grad", 1000)[0]["hbm_bytes_per_launch"] == 123.0
-    assert bench.committed_counters("grad", 2000) == (None, "committed PMC profile is for E=1000")
-    (prof / "traffic_grad.json").write_text(json.dumps(dict(rec, source_sha="0" * 16)))
+    assert bench.committed_counters("grad", 2000)[0] is None
+    (prof / "traffic_grad.json").write_text(json.dumps(rec))
+    assert bench.committed_counters("grad", 1_000_000) == (None, "committed PMC profile is for E=1000")
+    (prof / "traffic_grad_E1000.json").write_text(json.dumps(dict(rec, source_sha="0" * 16)))
     got, note = bench.committed_counters("grad", 1000)
     assert got is None and "kernel sources" in note
     assert bench.committed_counters("div", 1000)[0] is None

@@ -269,3 +269,65 @@ def test_write_through_and_non_temporal_stores_give_the_same_bits(cases, name):
                 assert torch.equal(results[0][n], results[1][n]), (name, E, n)
     finally:
         assert _hip.set_write_through_mib(before) == 1 << 20
+
+
+@pytest.mark.gpu
+def test_a_recaptured_operator_gives_its_groups_back(cases):
+    """Round 5: the counter groups a capture's launches own come back when the graph is destroyed
+    (fe_graph_retired through BoundOperator.release_graph), so an application that captures again every step never runs out of
+    groups; `exhausted` / `static_fallbacks` of fe_tail_stats would say so if it did.  300 captures > the 256 groups a device
+    may hold; every replay bitwise the static walk."""
+    torch, exprs, devs, static = cases
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        outs = _outputs(torch, exprs["grad"])
+        op = f.bind_operator([(exprs["grad"], devs["grad"])], 0, out_dicts=[outs])
+        s0 = _hip.tail_stats()
+        op.capture()
+        s1 = _hip.tail_stats()
+        assert s1["captured"] == s0["captured"] + 1 and s1["live_captures"] == s0["live_captures"] + 1
+        for rep in range(300):
+            op.capture()                      # releases the previous graph's group first
+            if rep % 50 == 0:
+                outs["_fe_out"].fill_(float("nan"))
+                op.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(outs["_fe_out"], static["grad"]["_fe_out"]), rep
+        s2 = _hip.tail_stats()
+        assert s2["captured"] == s1["captured"] and s2["exhausted"] == s0["exhausted"] and s2["static_fallbacks"] == s0["static_fallbacks"], (s0, s2)
+        assert op.release_graph() == 1 and op.release_graph() == 0
+        s3 = _hip.tail_stats()
+        assert s3["captured"] == s0["captured"] and s3["live_captures"] == s0["live_captures"]
+        del op
+    finally:
+        _hip.set_tail_rounds(before)
+    assert _hip.tail_check()["dirty_words"] == 0
+
+
+@pytest.mark.gpu
+def test_after_a_hip_error_the_first_dynamic_launch_verifies_its_group(cases):
+    """Round 5: the zero-between-launches invariant is no longer trusted blindly after an error.
+    Any FE_EHIP return of the process makes every stream's next dynamic launch wait for the stream once and verify (repair) its
+    counter group.  Here: a stale ticket planted by hand, then an FE_EHIP return (properties of a device that does not exist) --
+    the next launch finds and repairs the ticket and computes the right bits; without the error nothing is checked."""
+    torch, exprs, devs, static = cases
+    import ctypes as C
+
+    before = _hip.set_tail_rounds(1 << 20)
+    try:
+        f.evaluate(exprs["grad"], 0, devs["grad"], wait=True)          # the default stream owns a group
+        s0 = _hip.tail_stats()
+        lib = _hip.load_library()
+        assert lib.fe_device_info(99, None, 0, None, None) == -3        # FE_EHIP: no such device (not a sticky error)
+        assert _hip.tail_stats()["hip_errors"] == s0["hip_errors"] + 1
+        _hip.tail_plant(int(torch.cuda.current_stream().cuda_stream), 7)
+        out = f.evaluate(exprs["grad"], 0, devs["grad"], wait=True)["_fe_out"]
+        s1 = _hip.tail_stats()
+        assert s1["verified_after_error"] == s0["verified_after_error"] + 1 and s1["repaired_after_error"] == s0["repaired_after_error"] + 1
+        assert torch.equal(out, static["grad"]["_fe_out"])
+        out = f.evaluate(exprs["grad"], 0, devs["grad"], wait=True)["_fe_out"]     # verified once, not again
+        assert _hip.tail_stats()["verified_after_error"] == s1["verified_after_error"]
+        assert torch.equal(out, static["grad"]["_fe_out"])
+    finally:
+        _hip.set_tail_rounds(before)
+    assert _hip.tail_check()["dirty_words"] == 0

@@ -103,13 +103,14 @@ static int ab_main(int argc, char** argv) {
     typedef int (*clk_fn)(unsigned long long*);
     clk_fn rd = (clk_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_clock");
     for (size_t v = 0; v < variants.size() && rd; ++v)
-        if (variants[v] % 100000 >= 1000 && ((variants[v] % 100000 - 1000) & 32)) {
+        if (variants[v] % 100000 >= 1000 && ((variants[v] % 100000 - 1000) & (fam == "div" ? 128 : 32))) {
             set_variant(variants[v]);
             FE(fe_time_launches(family, &a, launches, nullptr, &ms));
             unsigned long long c[2];
             rd(c);
-            printf("variant %d: wave 0 main loop %llu shader cycles in %.1f us -> in-kernel clock %.0f MHz\n",
-                   variants[v], c[0], c[1] / 100.0, (double)c[0] / (double)c[1] * 100.0);
+            if (fam != "div")
+                printf("variant %d: wave 0 main loop %llu shader cycles in %.1f us -> in-kernel clock %.0f MHz\n",
+                       variants[v], c[0], c[1] / 100.0, (double)c[0] / (double)c[1] * 100.0);
             typedef int (*st_fn)(unsigned long long*, int);
             st_fn rs = (st_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_stamps");
             if (rs) {
@@ -133,6 +134,24 @@ static int ab_main(int argc, char** argv) {
                         fprintf(f, "\n");
                     }
                     fclose(f);
+                    // per-tile stamps (fe_dbg_tile): <file>.tiles.csv, microseconds after the first wave's entry, -1 = not reached
+                    st_fn rt = (st_fn)dlsym(RTLD_DEFAULT, "fe_dbg_read_tiles");
+                    if (rt) {
+                        std::vector<unsigned long long> tl(2048 * 16, 0);
+                        rt(tl.data(), 2048);
+                        const std::string name = std::string(getenv("FE_DUMP_STAMPS")) + ".tiles.csv";
+                        FILE* g = fopen(name.c_str(), "w");
+                        fprintf(g, "wave,xcc,hw_id,entry_us,loop_end_us,tiles");
+                        for (int k = 0; k < 16; ++k) fprintf(g, ",t%d_%d", k / 4, k % 4);
+                        fprintf(g, "\n");
+                        for (int w = 0; w < 2048; ++w) {
+                            fprintf(g, "%d,%llu,%llu,%.2f,%.2f,%llu", w, st4[4 * w + 3] & 0xff, (st4[4 * w + 3] >> 8) & 0xffffffffull,
+                                    (st4[4 * w] - tmin) / 100.0, (st4[4 * w + 2] - tmin) / 100.0, st4[4 * w + 3] >> 40);
+                            for (int k = 0; k < 16; ++k) fprintf(g, ",%.2f", tl[16 * w + k] >= tmin ? (tl[16 * w + k] - tmin) / 100.0 : -1.0);
+                            fprintf(g, "\n");
+                        }
+                        fclose(g);
+                    }
                 }
                 unsigned long long t0 = ~0ull, e_max = 0, l_min = ~0ull, l_max = 0, end_min = ~0ull, end_max = 0;
                 std::vector<double> loop_us, end_us;

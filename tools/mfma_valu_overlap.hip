@@ -11,17 +11,39 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-#ifdef MFMA_F32   // the same probe with v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles too)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+// CONTROL (round 5): the same harness on the bf16 MFMAs for which /opt/skills/guides/MI355X_MICROARCH.md (rows 'vector-instruction
+// ISSUE cost' and 'single-issue instructions HIDDEN per v_mfma_f32_32x32x16_bf16 gap') documents that a wave's own VALU
+// instructions DO hide: issue costs summing to <= 24 cycles in a 32-cycle gap.  If this harness reproduces that, its finding for
+// the 64-cycle f64 / f32 MFMAs (nothing of the wave's own VALU work hides) is a property of those instructions, not of the harness.
+#if defined(MFMA_BF16_32)
+#define ACC_T v16f
+#define ACC_ZERO {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define MFMA_ASM "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+#define AB_T v8s
+#define AB_INIT(x) v8s{0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3e80, 0x3f80, (short)(0x3f00 + ((int)(x) & 1))}
+#define MFMA_NAME "v_mfma_f32_32x32x16_bf16 (control: 8 passes = 32 cycles)"
+#elif defined(MFMA_BF16_16)
+#define ACC_T v4f
+#define ACC_ZERO {0, 0, 0, 0}
+#define MFMA_ASM "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+#define AB_T v8s
+#define AB_INIT(x) v8s{0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3e80, 0x3f80, (short)(0x3f00 + ((int)(x) & 1))}
+#define MFMA_NAME "v_mfma_f32_16x16x32_bf16 (control: 4 passes = 16 cycles)"
+#elif defined(MFMA_F32)   // the same probe with v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles too)
 #define ACC_T v16f
 #define ACC_ZERO {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define MFMA_ASM "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
 #define AB_T float
+#define AB_INIT(x) (float)(x)
 #define MFMA_NAME "v_mfma_f32_32x32x2_f32"
 #else
 #define ACC_T v4d
 #define ACC_ZERO {0, 0, 0, 0}
 #define MFMA_ASM "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
 #define AB_T double
+#define AB_INIT(x) (double)(x)
 #define MFMA_NAME "v_mfma_f64_16x16x4_f64"
 #endif
 
@@ -37,7 +59,7 @@ __global__ __launch_bounds__(512) void probe(double* sink, int iters, int second
     const bool mfma_wave = __builtin_amdgcn_readfirstlane(wave) < 4;   // waves 4..7 (when launched): side work only (wave-uniform: scalar branches)
     ACC_T acc0 = ACC_ZERO, acc1 = acc0, acc2 = acc0;
     double a = 1.0 + lane * 1e-3, b = 2.0 - lane * 1e-3;
-    AB_T ma = (AB_T)a, mb = (AB_T)b;
+    AB_T ma = AB_INIT(a), mb = AB_INIT(b);
     double f[16];
     float g[16];
     unsigned h[16];
@@ -117,8 +139,10 @@ int main() {
     run<0, 0>("nothing", sink);
     run<2, 0>("v_fma_f64 (independent)", sink); run<4, 0>("v_fma_f64 (independent)", sink); run<8, 0>("v_fma_f64 (independent)", sink); run<16, 0>("v_fma_f64 (independent)", sink);
     run<4, 4>("v_fma_f64 (one chain)", sink); run<8, 4>("v_fma_f64 (one chain)", sink);
-    run<4, 1>("v_fma_f32", sink); run<8, 1>("v_fma_f32", sink); run<16, 1>("v_fma_f32", sink);
-    run<4, 2>("v_add_u32", sink); run<8, 2>("v_add_u32", sink); run<16, 2>("v_add_u32", sink);
+    run<1, 1>("v_fma_f32", sink); run<2, 1>("v_fma_f32", sink); run<3, 1>("v_fma_f32", sink); run<4, 1>("v_fma_f32", sink); run<5, 1>("v_fma_f32", sink);
+    run<6, 1>("v_fma_f32", sink); run<8, 1>("v_fma_f32", sink); run<16, 1>("v_fma_f32", sink);
+    run<1, 2>("v_add_u32", sink); run<2, 2>("v_add_u32", sink); run<3, 2>("v_add_u32", sink); run<4, 2>("v_add_u32", sink); run<5, 2>("v_add_u32", sink);
+    run<6, 2>("v_add_u32", sink); run<8, 2>("v_add_u32", sink); run<16, 2>("v_add_u32", sink);
     run<4, 5>("ds_write_b64 + wait", sink); run<8, 5>("ds_write_b64 + wait", sink);
     run<2, 3>("ds_read_b64 + wait", sink); run<4, 3>("ds_read_b64 + wait", sink); run<8, 3>("ds_read_b64 + wait", sink);
     printf("# two waves per SIMD: wave A = MFMA + N side instructions, wave B = N side instructions only\n");

@@ -6,12 +6,12 @@ rm -rf "$out" && mkdir -p "$out" "$keep"
 cd /tmp && export TMPDIR=/tmp
 G1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 G2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_MISC SQ_INSTS_SALU"
-for fam in grad div facemass; do
-  for np in 56 35; do
+for fam in ${FAMS:-grad div facemass}; do
+  for np in ${NPS:-56 35}; do
     n=0
     for group in "$G1" "$G2"; do
       n=$((n+1))
-      rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$out/${fam}_${np}_$n" -o pmc -- python3 "$repo/tools/run_family.py" $fam $np 1000000 10 \
+      rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$out/${fam}_${np}_$n" -o pmc -- python3 "$repo/tools/run_family.py" $fam $np 1000000 ${LAUNCHES:-10} \
         > "$out/${fam}_${np}_$n.out" 2> "$out/${fam}_${np}_$n.err" || { tail -5 "$out/${fam}_${np}_$n.err"; exit 1; }
     done
   done
@@ -19,14 +19,15 @@ done
 python3 - "$out" > "$keep/summary.txt" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-for fam in ("grad", "div", "facemass"):
-    for np_ in (56, 35):
+import os
+for fam in os.environ.get("FAMS", "grad div facemass").split():
+    for np_ in [int(x) for x in os.environ.get("NPS", "56 35").split()]:
         vals = collections.defaultdict(list); dur = []
         for d in sorted(glob.glob(f"{out}/{fam}_{np_}_*/")):
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 seen = set()
                 for r in csv.DictReader(open(f)):
-                    if "mfma_kernel" not in r["Kernel_Name"]:
+                    if "fe::" not in r["Kernel_Name"] or "split_probe" in r["Kernel_Name"] or "generic" in r["Kernel_Name"]:
                         continue
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     if r["Dispatch_Id"] not in seen:

@@ -73,7 +73,7 @@ def main() -> None:
 
     rec = {"workload": workload, "E": E, "kernel": kernel, "source_sha": bench.kernel_source_sha(),
            "profile": "rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python3 bench.py "
-                      f"--workload {workload} --no-cpu-baseline --no-protocol --setup-launches 3 --setup-seconds 0 --steps 10 --warmup 2, default placement "
+                      f"--workload {workload} --no-cpu-baseline --no-protocol --setup-launches 3 --setup-seconds 0 --steps 10 --warmup 2 --elems-per-gpu {E}, default placement "
                       "(outputs from the split allocator; tools/profile_round.sh)",
            "dispatches_per_pass": ndisp[kernel], "counters": c}
     if mean("FETCH_SIZE") is not None:
