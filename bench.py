@@ -243,7 +243,40 @@ def kernel_source_sha() -> str:
             continue
         h.update(p.name.encode())
         h.update(strip_c_comments(p.read_text(errors="replace")).encode())
+    # ... and how they are compiled: the flags of __graft_entry__.build_library and the compiler's version (round 5: another
+    # optimisation level or another hipcc is another binary, whatever the sources say)
+    h.update(("flags:" + " ".join(_build_flags())).encode())
+    h.update(("compiler:" + _compiler_version()).encode())
     return h.hexdigest()[:16]
+
+
+def _build_flags():
+    try:
+        import __graft_entry__ as entry
+
+        return list(entry.HIPCC_FLAGS)
+    except Exception:      # noqa: BLE001
+        return ["unknown"]
+
+
+_COMPILER_VERSION = None
+
+
+def _compiler_version() -> str:
+    """First lines of ``hipcc --version`` (HIP version and the clang it drives), or "unknown"; asked once."""
+    global _COMPILER_VERSION
+    if _COMPILER_VERSION is None:
+        import shutil
+        import subprocess
+
+        exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        try:
+            out = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout
+            keep = [ln.strip() for ln in out.splitlines() if ln.startswith(("HIP version", "AMD clang version", "clang version"))]
+            _COMPILER_VERSION = " | ".join(keep) or "unknown"
+        except Exception:  # noqa: BLE001
+            _COMPILER_VERSION = "unknown"
+    return _COMPILER_VERSION
 
 
 def committed_counters(workload: str, E: int):
@@ -695,6 +728,7 @@ def main() -> None:
 
     timed = timed_region(step_batch, args.steps, sync, device)
     wall_s, kernel_s = timed["wall"], timed["kernel"]
+    launch_info = _hip.last_launch_info()      # what the launcher decided for the timed launches (fe_last_launch_info)
     pool_r = placement_report.get("pool") or {}
     per_rank = gather_rank_reports({"elements": E, "kernel_ms": timed["local_kernel"] / args.steps * 1e3, "wall_ms": timed["local_wall"] / args.steps * 1e3,
                                     "placement_mode": ("split" if placement_report.get("mode") == "split" else
@@ -740,24 +774,28 @@ def main() -> None:
             static_walk_ms = step_batch(args.steps) / args.steps * 1e3
     finally:
         _hip.set_tail_rounds(rounds_setting)
-    walk_report = {"mode": "static" if rounds_setting < 0 else "tickets behind two static rounds (launches of four and a half or more rounds)",
-                   "dynamic_rounds": "all" if rounds_setting >= (1 << 20) else rounds_setting,
-                   "kernel_ms_static_walk": None if static_walk_ms is None else round(static_walk_ms, 5)}
+    dyn = bool(launch_info.get("dynamic_walk"))
+    walk_report = {"mode": "tickets behind the static rounds" if dyn else "static",
+                   "tiles": launch_info.get("tiles"), "static_tiles": launch_info.get("static_tiles"),
+                   "grid": [launch_info.get("blocks"), launch_info.get("waves_per_block")], "kernel": launch_info.get("kind"),
+                   "rule": "tickets in launches of four and a half or more rounds (fe_set_tail_rounds: %s)" % ("all" if rounds_setting >= (1 << 20) else rounds_setting),
+                   # (the A/B is a different launch only when the timed one walked dynamically)
+                   "kernel_ms_static_walk": None if (static_walk_ms is None or not dyn) else round(static_walk_ms, 5)}
 
     want_gather = parallel.in_group() and args.gather_fields == "on"
     # A/B outside the timed region: the streamed operand fetched the other way (plain loads while the launch's inputs fit the
     # Infinity Cache, non-temporal otherwise: feinsum_amd/csrc/fe_common.h, fe_set_temporal_loads_mib)
     in_bytes = sum(int(t.numel()) * t.element_size() for t in {id(t): t for _, d in stages for t in d.values()}.values())
     mib_setting = _hip.set_temporal_loads_mib(0)
-    floor = {"div": 80, "facemass": 64}.get(args.workload, 0) << 20       # (single div / face-mass launches: measured floors)
-    plain = floor <= in_bytes <= (mib_setting << 20) and in_bytes > 0
+    plain = bool(launch_info.get("temporal_loads"))       # (the launcher's own decision, not a re-derivation of its rule)
     loads_report = {"threshold_mib": mib_setting, "launch_input_mib": round(in_bytes / 2**20, 1),
                     "streamed_operand": "plain loads (the launch's inputs fit the 256 MiB Infinity Cache: a repeated launch finds them there)"
                     if plain else "non-temporal loads"}
     try:
         if not args.no_protocol and plain:
             step_batch(max(args.warmup, 10))
-            loads_report["kernel_ms_non_temporal_loads"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
+            if not _hip.last_launch_info().get("temporal_loads"):     # the A/B launch really ran the other way
+                loads_report["kernel_ms_non_temporal_loads"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
     finally:
         _hip.set_temporal_loads_mib(mib_setting)
 
@@ -765,16 +803,14 @@ def main() -> None:
     # of at most fe_set_write_through_mib MiB -- non-temporal otherwise: feinsum_amd/csrc/fe_common.h)
     out_bytes = sum(int(t.numel()) * t.element_size() for t in outs_all)
     wt_setting = _hip.set_write_through_mib(0)
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
-    tiles, waves = E // 16, 8 * cus                                           # (the launcher's rule for p = 4: feinsum_hip.hip, tail_static_tiles)
-    static_launch = rounds_setting < 0 or tiles // waves < 4 or (tiles // waves == 4 and (tiles - 4 * waves) * 2 < waves)
-    write_through = args.workload == "grad" and 0 < out_bytes <= (wt_setting << 20) and static_launch
+    write_through = bool(launch_info.get("write_through_stores"))
     stores_report = {"threshold_mib": wt_setting, "launch_output_mib": round(out_bytes / 2**20, 1),
                      "policy": "write-through (a short launch: nothing dirty left in the L2s at its end)" if write_through else "non-temporal"}
     try:
         if not args.no_protocol and write_through:
             step_batch(max(args.warmup, 10))
-            stores_report["kernel_ms_non_temporal_stores"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
+            if not _hip.last_launch_info().get("write_through_stores"):
+                stores_report["kernel_ms_non_temporal_stores"] = round(step_batch(args.steps) / args.steps * 1e3, 5)
     finally:
         _hip.set_write_through_mib(wt_setting)
 

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
     "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
-    "fe_set_cu_limit", "fe_set_wide_blocks", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
+    "fe_set_cu_limit", "fe_set_wide_blocks", "fe_set_phase_priority", "fe_set_phase_priority_p5", "fe_last_launch_info", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -177,6 +177,12 @@ def load_library() -> C.CDLL:
     lib.fe_set_write_through_mib.argtypes = [C.c_int32]
     lib.fe_set_cu_limit.restype = C.c_int
     lib.fe_set_cu_limit.argtypes = [C.c_int32]
+    lib.fe_last_launch_info.restype = C.c_int
+    lib.fe_last_launch_info.argtypes = [C.POINTER(C.c_int64), C.c_int32]
+    lib.fe_set_phase_priority.restype = C.c_int64
+    lib.fe_set_phase_priority.argtypes = [C.c_int64]
+    lib.fe_set_phase_priority_p5.restype = C.c_int
+    lib.fe_set_phase_priority_p5.argtypes = [C.c_int32]
     lib.fe_set_wide_blocks.restype = C.c_int
     lib.fe_set_wide_blocks.argtypes = [C.c_int64]
     lib.fe_stream_retired.restype = C.c_int
@@ -483,6 +489,36 @@ def graph_retired(cid: int) -> int:
 def tail_plant(stream: int, value: int) -> None:
     """Test hook (fe_tail_plant): leave a stale ticket in the counter group of *stream*."""
     check(load_library().fe_tail_plant(stream, int(value)))
+
+
+_LAST_LAUNCH = ("valid", "dynamic_walk", "temporal_loads", "write_through_stores", "blocks", "waves_per_block", "kind", "bodies", "tiles",
+                "static_tiles")
+
+
+def last_launch_info() -> dict:
+    """What the launcher decided for the MFMA launch this thread enqueued last (fe_last_launch_info): the walk, the cache hints
+    of loads and stores, the grid.  ``{}`` before the first such launch."""
+    buf = (C.c_int64 * len(_LAST_LAUNCH))()
+    n = int(load_library().fe_last_launch_info(buf, len(_LAST_LAUNCH)))
+    if n < 0:
+        check(n)
+    d = {k: int(buf[i]) for i, k in enumerate(_LAST_LAUNCH[:n])}
+    if not d.get("valid"):
+        return {}
+    d["phase_priority"] = bool(d["kind"] & 2)
+    d["kind"] = "sixteen waves per CU" if d["kind"] & 1 else "default"
+    return d
+
+
+def set_phase_priority(tiles: int) -> int:
+    """grad / div launches of at most *tiles* tiles per body run their f64 VALU phases at raised issue priority
+    (fe_set_phase_priority; 0 = never); returns the previous setting.  A tuning knob -- results do not depend on it."""
+    return int(load_library().fe_set_phase_priority(int(tiles)))
+
+
+def set_phase_priority_p5(on: bool) -> bool:
+    """Phase priorities in the eight-wave p = 5 kernels (fe_set_phase_priority_p5); returns the previous setting."""
+    return bool(load_library().fe_set_phase_priority_p5(1 if on else 0))
 
 
 def set_wide_blocks(tiles: int) -> int:

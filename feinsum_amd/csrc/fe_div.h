@@ -132,6 +132,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
     const bool tload = (op_flags & kOpLoadsTemporal) != 0;   // the u planes by plain loads (fe_common.h)
+    const bool phase_prio = (op_flags & kOpPhasePriority) != 0;   // short launches: the B build at raised priority (fe_common.h)
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,6 +332,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                         asked8 = true;
                     }
                 }
+                if (phase_prio) __builtin_amdgcn_s_setprio(3);   // f64 VALU phase: the B fragments (fe_common.h, kOpPhasePriority)
                 double jac[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
@@ -365,6 +367,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                 issue_plane(tile, fk, 2, lds_a);
                 wait_vmcnt<0>();
                 add_plane(2);
+                if (phase_prio) __builtin_amdgcn_s_setprio(0);   // matrix phase
 
                 v4d acc[G::BT];
                 double accs[G::NS > 0 ? G::NS : 1];
@@ -605,6 +608,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             const unsigned long long c0 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
             if constexpr (!kRegPre) wait_vmcnt<0>();
+            if (phase_prio) __builtin_amdgcn_s_setprio(0);   // matrix phase (fe_common.h, kOpPhasePriority)
             bool asked8 = false;
             if constexpr (kDyn) {
                 if (dyn8 && !(tile < t_static && tile + stride < t_static)) {   // the next tile is not static
@@ -666,6 +670,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
             double* ob = L->u[0];   // every B value is in a register by now (the MFMAs consumed them)
             bool requested = false;
+            if (phase_prio) __builtin_amdgcn_s_setprio(3);   // f64 VALU phase: the Jacobian contraction of the planes
 #ifdef FE_EXPERIMENTS
             const unsigned long long c2 = (kDbg & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -804,7 +809,8 @@ __device__ __forceinline__ void div3d_mfma_body(
     bool pending = false, reported = false;
     auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
     while (tile < tEnd) {
-        balance_priority(younger_half, iteration++);
+        if (!phase_prio) balance_priority(younger_half, iteration);
+        ++iteration;
         const int64_t e0 = phys(tile) * G::TEL;
         double* const out = field_out(P, fk);
         const bool next_new_tile = (fk + 1 == nb);
@@ -815,6 +821,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         else wait_vmcnt<G::STORES>();
         first = false;
         FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
+        if (phase_prio) __builtin_amdgcn_s_setprio(3);                           // f64 VALU phase: the B fragments
 
         // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
         double bfrag[M][G::KSJ][G::NBF];
@@ -904,6 +911,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
         }
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
+        if (phase_prio) __builtin_amdgcn_s_setprio(0);                           // matrix phase
         FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // B fragments built, the next unit's loads issued
         if constexpr ((kDbg & 64) != 0 && MODE == 0 && ND == 3 && M == 1) {
             // experiment (kDbg & 64): touch the tile AFTER next -- one dword per 128-byte line of its three planes and nine J rows --

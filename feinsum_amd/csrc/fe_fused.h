@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_ker
     // (Two straight-line sequences, not a loop over the bodies: in a loop the register allocator keeps state of one
     // body alive across the other and spills -- 408 bytes of scratch per lane and 4.7 % more HBM traffic, measured.)
     const bool swap = ((opT & 256) && blockIdx.x >= gridDim.x / 2) || ((opT & 512) && (blockIdx.x & 1));
-    const int op = opT & (1 | kOpLoadsTemporal);
+    const int op = opT & (1 | kOpLoadsTemporal | kOpPhasePriority);
 #ifdef FE_EXPERIMENTS
     if ((opT & 1024) && gridDim.x >= 2 && (gridDim.x & 1) == 0) {
         // ROLE SPLIT (bit 10; experiment build only -- measured in round 3 and 0.5 % slower): the older half of the grid runs div over ALL tiles,

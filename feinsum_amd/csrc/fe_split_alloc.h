@@ -94,8 +94,10 @@ constexpr int kSplitMaxClasses = 3;                 // three superclasses on MI3
 #define FE_SPLIT_CHECK(expr)                                                                        \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
-        if (_e != hipSuccess)                                                                       \
+        if (_e != hipSuccess) {                                                                     \
+            (void)hipGetLastError();                                                                \
             return fail(FE_EHIP, "split allocator: %s failed: %s", #expr, hipGetErrorString(_e));   \
+        }                                                                                           \
     } while (0)
 
 struct SplitPiece {

@@ -46,11 +46,15 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// (a failed call is reported once: HIP's per-thread "last error" is cleared here, or the launch after it -- which ends with
+//  FE_HIP_CHECK(hipGetLastError()) -- would report the same, already handled error again)
 #define FE_HIP_CHECK(expr)                                                             \
     do {                                                                               \
         hipError_t _e = (expr);                                                        \
-        if (_e != hipSuccess)                                                          \
+        if (_e != hipSuccess) {                                                        \
+            (void)hipGetLastError();                                                   \
             return fail(FE_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+        }                                                                              \
     } while (0)
 
 // Persistent-style grid: enough blocks to fill every CU at the kernel's
@@ -362,6 +366,37 @@ int write_through_flag(int64_t output_bytes) {
     return output_bytes <= g_write_through_output_bytes.load(std::memory_order_relaxed) ? fe::kOpStoresWriteThrough : 0;
 }
 
+// kOpPhasePriority (fe_common.h) for a launch of `nTiles` tiles per body: launches of at most so many tiles
+// ($FEINSUM_PHASE_PRIORITY_TILES / fe_set_phase_priority; 0 = never)
+std::atomic<long long> g_phase_priority_tiles{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_TILES"); return e ? atoll(e) : 0ll; }()};
+// the same flag for the eight-wave p = 5 kernels (compute bound at every size): $FEINSUM_PHASE_PRIORITY_P5 / fe_set_phase_priority_p5
+std::atomic<int> g_phase_priority_p5{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_P5"); return e ? atoi(e) : 0; }()};
+int phase_priority_flag_p5() { return g_phase_priority_p5.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0; }
+int phase_priority_flag(int64_t nTiles) {
+    return nTiles <= g_phase_priority_tiles.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0;
+}
+
+// What the launcher decided for the MFMA launch enqueued last by this thread (fe_last_launch_info): bench.py and the tools report
+// these instead of re-deriving the rules (round 4's report recomputed them in Python and could disagree with the kernel).
+struct LastLaunch {
+    int valid = 0, dynamic_walk = 0, temporal_loads = 0, write_through = 0, blocks = 0, waves_per_block = 0, kind = 0, bodies = 0;
+    long long tiles = 0, static_tiles = 0;
+};
+thread_local LastLaunch g_last_launch;
+void note_launch(bool dynamic, int flags, unsigned blocks, int waves_per_block, int64_t tiles, int64_t static_tiles, int kind = 0, int bodies = 1) {
+    LastLaunch& L = g_last_launch;
+    L.valid = 1;
+    L.dynamic_walk = dynamic ? 1 : 0;
+    L.temporal_loads = (flags & fe::kOpLoadsTemporal) ? 1 : 0;
+    L.write_through = (!dynamic && (flags & fe::kOpStoresWriteThrough)) ? 1 : 0;
+    L.blocks = (int)blocks;
+    L.waves_per_block = waves_per_block;
+    L.kind = kind | ((flags & fe::kOpPhasePriority) ? 2 : 0);
+    L.bodies = bodies;
+    L.tiles = tiles;
+    L.static_tiles = dynamic ? static_tiles : tiles;
+}
+
 // Persistent-style grid for the per-wave-tile kernels: 2 blocks of 4 waves per
 // CU (their VGPR / LDS residency), fewer when there is less work.
 // (a per-wave-equal grid -- every wave the same number of tiles, on fewer waves -- was measured in round 3 and is slower at
@@ -386,6 +421,7 @@ int launch_grad_p5(const double* J, const double* D, const fe::FieldPtrs& P, int
                                 G::THREADS, G::BLOCKS_PER_CU);
     });
     if (attr_rc != FE_OK) return attr_rc;
+    opT |= phase_priority_flag_p5();
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
 #ifdef FE_EXPERIMENTS
 #define FE_P5_CASE(DBG)                                                                                                   \
@@ -464,6 +500,7 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
                                     G::THREADS, G::BLOCKS_PER_CU);
         });
         if (attr_rc != FE_OK) return attr_rc;
+        opT |= phase_priority_flag_p5();
         const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = device_cu_count();
         const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
         if (nb == 1) {   // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
@@ -523,6 +560,7 @@ int launch_wide(const double* J, const double* D, const fe::FieldPtrs& P, int nb
     const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = 2 * (int64_t)device_cu_count();
     hipLaunchKernelGGL((fe::wide_w8_kernel<NP, MODE>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(G::THREADS), G::LDS_BYTES, s, J, D, P,
                        nb, E, nTiles, opT);
+    note_launch(false, opT, (unsigned)(blocks < cap ? blocks : cap), G::WAVES, nTiles, nTiles, 1);
     return FE_OK;
 }
 
@@ -591,7 +629,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + (int64_t)nb * NP) * E * 8);
+    opT |= temporal_flag((9 + (int64_t)nb * NP) * E * 8) | phase_priority_flag(nTiles);
     static PerDeviceOnce once_plain, once_prepared, once_planes;
     char what[64];
     const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
@@ -617,7 +655,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 20>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 64>, "experiment", G::LDS_BYTES, 256, 1);
-            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES, 256, 1);
+            configure_kernel(fe::grad3d_mfma_kernel<NP, M, 96>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 128>, "experiment", G::LDS_BYTES, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 32, true, true>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1);
             configure_kernel(fe::grad3d_mfma_kernel<NP, M, 0>, "grad (experiments build)", G::LDS_BYTES, 256, 2);
@@ -633,8 +671,13 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                            nTiles, opT);
         return FE_OK;
     }
+#ifdef FE_EXPERIMENTS
+#define FE_GRAD_LDS(DBG) (G::LDS_BYTES + (((DBG) & 32) ? fe::kDbgTileLdsBytes : 0))   // (the per-tile stamps live behind the kernel's own LDS)
+#else
+#define FE_GRAD_LDS(DBG) G::LDS_BYTES
+#endif
 #define FE_GRAD_CASE(DBG) \
-    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, G::LDS_BYTES, s, P, D, nullptr, nb, nx, E, nTiles, opT)
+    hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, DBG>), g, b, FE_GRAD_LDS(DBG), s, P, D, nullptr, nb, nx, E, nTiles, opT)
     switch (NP == 35 ? dbg : 0) {
 #ifdef FE_EXPERIMENTS
         case 1: FE_GRAD_CASE(1); break;
@@ -686,6 +729,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                             snprintf(what, sizeof(what), "grad Np=%d M=%d, dynamic walk", NP, M);
                             if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, 2)) return rc;
                             hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
+                            note_launch(true, opT, g.x, G::WAVES, nTiles, t_static);
                             break;
                         }
                         {   // b fields
@@ -694,6 +738,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                             if (int rc = configured(once_tail_b, fe::grad3d_mfma_tail_kernel<NP, M, 0, true>, what, G::LDS_BYTES, 256, 2)) return rc;
                             hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M, 0, true>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail,
                                                t_static);
+                            note_launch(true, opT, g.x, G::WAVES, nTiles, t_static);
                             break;
                         }
                     }
@@ -701,9 +746,11 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
             }
             if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (static walk, one field: a short launch)
             FE_GRAD_CASE(0);
+            note_launch(false, opT, g.x, G::WAVES, nTiles, nTiles);
             break;
     }
 #undef FE_GRAD_CASE
+#undef FE_GRAD_LDS
     return FE_OK;
 }
 
@@ -714,7 +761,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv);
+    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv) | phase_priority_flag(nTiles);
     static PerDeviceOnce once_plain, once_prepared;
     char what[64];
     int attr_rc;
@@ -773,6 +820,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                             snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
                             if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
                             hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
+                            note_launch(true, opT, g.x, G::WAVES, nTiles, t_static);
                             break;
                         }
                         {   // b fields
@@ -782,12 +830,14 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                                 return rc;
                             hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M, true>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail,
                                                t_static);
+                            note_launch(true, opT, g.x, G::WAVES, nTiles, t_static);
                             break;
                         }
                     }
                 }
             }
             FE_DIV_CASE(0);
+            note_launch(false, opT & ~fe::kOpStoresWriteThrough, g.x, G::WAVES, nTiles, nTiles);
             break;
     }
 #undef FE_DIV_CASE
@@ -904,11 +954,13 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
                 return rc;
             hipLaunchKernelGGL((fe::facemass_mfma_tail_kernel<NP, NFP, M, NB, NF>), dim3((unsigned)blocks), dim3(G::THREADS), G::LDS_BYTES, s,
                                J, R, P, E, nTiles, jfe, rifj, tail, t_static);
+            note_launch(true, jfe, (unsigned)blocks, G::WAVES, nTiles, t_static);
             return FE_OK;
         }
     }
     hipLaunchKernelGGL((fe::facemass_mfma_kernel<NP, NFP, M, NB, NF, ALDS, W8>), dim3((unsigned)blocks), dim3(G::THREADS),
                        G::LDS_BYTES, s, J, R, nullptr, P, E, nTiles, jfe, rifj);
+    note_launch(false, jfe & ~fe::kOpStoresWriteThrough, (unsigned)blocks, G::WAVES, nTiles, nTiles);
     return FE_OK;
 }
 
@@ -1043,7 +1095,7 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     }
     // body order (fe_fused.h): with the static walk the younger half of the grid runs grad first; with tickets every block
     // runs div, then grad (profiles/r03/dynamic_walk_fused.txt: 77.9 - 78.1 against 76.9 - 77.6 %)
-    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8);
+    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8) | phase_priority_flag(nTiles);
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
 #endif
@@ -1053,6 +1105,7 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     else
         hipLaunchKernelGGL((fe::graddiv3d_mfma_kernel<NP, MG, MD, false, kDyn>), dim3(grid), dim3(256), G::LDS_BYTES, s, J, D, nullptr,
                            Pg, Pd, E, nTilesG, nTilesD, op_arg, ft);
+    note_launch(ft.tail != nullptr, op_arg & fe::kOpLoadsTemporal, grid, 4, nTilesG + nTilesD, ft.static_d + ft.static_g, 0, 2);
     return FE_OK;
 }
 
@@ -1084,7 +1137,7 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
         if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
     }
     fe::WaveOpArgs args = a;
-    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8);
+    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8) | phase_priority_flag(nTiles);
     if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);
@@ -1095,6 +1148,8 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
     else
         hipLaunchKernelGGL((fe::waveop3d_mfma_kernel<NP, NFP, MG, MD, MF, NB, false, kDyn>), dim3(grid), dim3(256), G::LDS_BYTES, s,
                            args, Pg, Pd, Pf, ft);
+    note_launch(ft.tail != nullptr, args.load_flags & fe::kOpLoadsTemporal, grid, 4, a.nTilesG + a.nTilesD + a.nTilesF,
+                ft.static_d + ft.static_g + ft.static_f, 0, 3);
     return FE_OK;
 }
 
@@ -2109,6 +2164,23 @@ int fe_set_temporal_loads_mib(int32_t mib) {
 
 int fe_set_write_through_mib(int32_t mib) {
     return (int)(g_write_through_output_bytes.exchange(mib < 0 ? 0 : (long long)mib << 20) >> 20);
+}
+
+int fe_last_launch_info(int64_t* out, int32_t n) {
+    if (!out || n < 1) return fail(FE_EINVAL, "fe_last_launch_info: bad arguments");
+    const LastLaunch& L = g_last_launch;
+    const int64_t v[FE_LAST_LAUNCH_INFO] = {L.valid, L.dynamic_walk, L.temporal_loads, L.write_through, L.blocks, L.waves_per_block, L.kind, L.bodies,
+                                            L.tiles, L.static_tiles};
+    for (int k = 0; k < n && k < FE_LAST_LAUNCH_INFO; ++k) out[k] = v[k];
+    return n < FE_LAST_LAUNCH_INFO ? n : FE_LAST_LAUNCH_INFO;
+}
+
+int fe_set_phase_priority_p5(int32_t on) {
+    return g_phase_priority_p5.exchange(on ? 1 : 0);
+}
+
+int64_t fe_set_phase_priority(int64_t tiles) {
+    return g_phase_priority_tiles.exchange(tiles < 0 ? 0 : tiles);
 }
 
 int fe_set_wide_blocks(int64_t tiles) {

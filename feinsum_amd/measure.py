@@ -520,6 +520,10 @@ def _allocate_output(shape: Tuple[int, ...], dtype: Any, device: Any, transform:
         return torch.empty(shape, dtype=dtype, device=device), "torch"
     if _placement_mode(transform) != "split":
         return torch.empty(shape, dtype=dtype, device=device), "torch (placement: separate)"
+    if torch.cuda.is_current_stream_capturing():
+        # the allocator creates handles, probes with kernels of its own and may synchronise the device: none of that may
+        # happen inside a stream capture -- torch's allocator knows how to allocate for a graph
+        return torch.empty(shape, dtype=dtype, device=device), "torch (stream capture in progress)"
     try:
         return placement.empty(shape, dtype, device), "split"
     except (RuntimeError, HipLibraryError) as exc:

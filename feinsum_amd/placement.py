@@ -25,15 +25,94 @@ MIB = 1 << 20
 # (include/feinsum_hip.h, feinsum_amd/csrc/fe_split_alloc.h)
 # --------------------------------------------------------------------------
 
+# Arrays whose last tensor is gone are RECYCLED, not freed (round 5): an ``evaluate()`` that allocates its own
+# outputs would otherwise pay a VMM map (0.5-2 ms) per call and, on release, a ``hipDeviceSynchronize()`` plus an unmap --
+# against a 0.19 ms kernel -- and grow the process's reserved address space for ever (a range is never handed out twice:
+# fe_split_alloc.h).  A released array keeps its mapping and waits, with an event recorded on the releasing thread's current
+# stream, in a per-(device, size) list; the next ``empty`` of that size makes ITS current stream wait for the event (no host
+# synchronisation) and takes the array as it is.  The same stream-ordering assumption as torch's caching allocator: work on
+# other streams must have been ordered before the last tensor was dropped.  At most ``FEINSUM_SPLIT_RECYCLE_MIB`` (default
+# 4096) MiB wait per device; beyond that the oldest arrays are really freed.
+import logging as _logging
+import os as _os
+import threading as _threading
+from collections import deque as _deque
+
+_log = _logging.getLogger(__name__)
+_recycle_lock = _threading.RLock()      # (re-entrant: a garbage collection inside a locked region may run another __del__)
+_recycled: Dict[Any, Any] = {}          # (device index, nbytes) -> deque of (ptr, event)
+_recycled_bytes: Dict[int, int] = {}    # device index -> bytes waiting
+_recycle_stats = {"reused": 0, "freed": 0, "kept": 0, "free_failures": 0}
+
+
+def _recycle_cap() -> int:
+    return int(float(_os.environ.get("FEINSUM_SPLIT_RECYCLE_MIB", "4096")) * MIB)
+
+
+def recycle_stats() -> Dict[str, int]:
+    """Counters of the array recycling above: arrays ``reused`` / ``kept`` for reuse / really ``freed``, ``free_failures``,
+    and the bytes waiting per device."""
+    with _recycle_lock:
+        return dict(_recycle_stats, waiting_bytes=dict(_recycled_bytes))
+
+
+def recycle_trim(device_index: Any = None) -> int:
+    """Really free the arrays waiting for reuse (all devices, or one); returns how many."""
+    from feinsum_amd import _hip
+
+    with _recycle_lock:
+        keys = [k for k in _recycled if device_index is None or k[0] == device_index]
+        victims = [(k[0], ptr) for k in keys for ptr, _ in _recycled.pop(k)]
+        for k in keys:
+            _recycled_bytes[k[0]] = 0
+    n = 0
+    for dev, ptr in victims:
+        n += _really_free(_hip.split_free, dev, ptr)
+    return n
+
+
+def _really_free(free_fn: Any, device_index: int, ptr: int) -> int:
+    try:
+        import torch
+
+        with torch.cuda.device(device_index):
+            free_fn(ptr)             # waits for the device like hipFree, then unmaps
+        _recycle_stats["freed"] += 1
+        return 1
+    except Exception as exc:         # noqa: BLE001  (a failed free is a leak: say so -- not silently)
+        _recycle_stats["free_failures"] += 1
+        try:
+            _log.warning("fe_split_free(%#x) on device %d failed: %s -- the array's memory stays mapped", ptr, device_index, str(exc)[:200])
+        except Exception:            # noqa: BLE001  (interpreter shutdown: logging may be gone)
+            pass
+        return 0
+
+
 class _SplitBuffer:
     """Owner of one ``fe_split_alloc`` array; torch reads it through ``__cuda_array_interface__`` and keeps this
-    object alive for as long as any tensor (or view) of the array lives; the memory returns to the pool with it."""
+    object alive for as long as any tensor (or view) of the array lives; the array is recycled (see above) with it."""
 
     def __init__(self, nbytes: int, device_index: int) -> None:
+        import torch
+
         from feinsum_amd import _hip
 
-        self.ptr, self.nbytes, self.device_index = _hip.split_alloc(nbytes), int(nbytes), int(device_index)
+        self.nbytes, self.device_index = int(nbytes), int(device_index)
         self._free = _hip.split_free     # (bound now: module globals may be gone at interpreter exit)
+        self.ptr = 0
+        with _recycle_lock:
+            waiting = _recycled.get((self.device_index, self.nbytes))
+            if waiting:
+                self.ptr, event = waiting.popleft()
+                _recycled_bytes[self.device_index] -= self.nbytes
+                _recycle_stats["reused"] += 1
+            else:
+                event = None
+        if self.ptr:
+            if event is not None:
+                torch.cuda.current_stream(self.device_index).wait_event(event)   # stream-ordered: no host synchronisation
+        else:
+            self.ptr = _hip.split_alloc(nbytes)
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (self.ptr, False),
                                          "version": 3, "strides": None}
 
@@ -41,13 +120,31 @@ class _SplitBuffer:
         ptr, self.ptr = getattr(self, "ptr", 0), 0
         if not ptr:
             return
+        victims = []
         try:
             import torch
 
-            with torch.cuda.device(self.device_index):
-                self._free(ptr)          # waits for the device like hipFree, then unmaps
-        except Exception:                # noqa: BLE001  (interpreter shutdown: the process is going away anyway)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("stream capture in progress")      # no event may be recorded now: free below (after the capture it syncs)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(self.device_index))
+            with _recycle_lock:
+                _recycled.setdefault((self.device_index, self.nbytes), _deque()).append((ptr, event))
+                _recycled_bytes[self.device_index] = _recycled_bytes.get(self.device_index, 0) + self.nbytes
+                _recycle_stats["kept"] += 1
+                cap = _recycle_cap()
+                while _recycled_bytes[self.device_index] > cap:     # the oldest arrays of the largest waiting size go
+                    key = max((k for k in _recycled if k[0] == self.device_index and _recycled[k]), key=lambda k: k[1], default=None)
+                    if key is None:
+                        break
+                    old_ptr, _ = _recycled[key].popleft()
+                    _recycled_bytes[self.device_index] -= key[1]
+                    victims.append(old_ptr)
+            ptr = 0
+        except Exception:                # noqa: BLE001  (interpreter shutdown, capture: free it now)
             pass
+        for v in victims + ([ptr] if ptr else []):
+            _really_free(self._free, self.device_index, v)
 
 
 def empty(shape: Sequence[int], dtype: Any = None, device: Any = None, *, written: bool = True) -> Any:

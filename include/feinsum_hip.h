@@ -442,6 +442,22 @@ int fe_set_temporal_loads_mib(int32_t mib);
  * the end of the launch to write back (E = 1e5: 24.0 -> 23.3 us).  Returns the previous setting.  Results do not depend on it. */
 int fe_set_write_through_mib(int32_t mib);
 
+/* What the launcher decided for the MFMA launch this THREAD enqueued last (p = 1..4 grad / div / face-mass and the fused
+ * launches; other paths leave it unchanged): out[0..n) = {valid, dynamic walk (tickets behind the static rounds), plain
+ * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 0: sixteen waves
+ * per CU; bit 1: phase priorities), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
+ * written.  For reports (bench.py prints these instead of re-deriving the launcher's rules). */
+#define FE_LAST_LAUNCH_INFO 10
+int fe_last_launch_info(int64_t* out, int32_t n);
+
+/* Phase priorities in short launches: p = 1..4 grad / div launches (and the fused launches' grad / div bodies) of at most
+ * `tiles` 16 M-element tiles per body run their f64 VALU phases (div: the B-fragment build; grad: the Jacobian contraction) at
+ * raised issue priority and their matrix phases at priority 0 (0 = never; also FEINSUM_PHASE_PRIORITY_TILES).  Returns the
+ * previous setting.  Results do not depend on it. */
+int64_t fe_set_phase_priority(int64_t tiles);
+/* ... and the same for the eight-wave kernels of tetrahedra p = 5 (grad, div), at every size (FEINSUM_PHASE_PRIORITY_P5). */
+int fe_set_phase_priority_p5(int32_t on);
+
 /* Short launches of p = 4 grad / div (one field) on the sixteen-waves-per-CU kernels (operator fragments in LDS, two
  * eight-wave blocks per CU): launches of at most `tiles` 16-element tiles (0 = never, 1 = always; also FEINSUM_WIDE_BLOCKS).
  * Returns the previous setting.  Results agree with the default kernels to rounding (another summation order of r). */

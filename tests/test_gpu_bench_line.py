@@ -74,7 +74,12 @@ def test_bench_default_placement(workload, placement):
     line = _json_line(out.stdout)
     assert line["placement"]["mode"] == placement and line["result_finite"] and line["value"] > 0
     assert line["kernel_ms_separate_allocations"] > 0            # the A/B against torch allocations stays in the line
-    assert line["walk"]["kernel_ms_static_walk"] > 0 and line["walk"]["dynamic_rounds"] == "all"   # ... and the A/B of the walks
+    assert line["walk"]["kernel_ms_static_walk"] > 0 and line["walk"]["mode"].startswith("tickets")   # ... and the A/B of the walks
+    # (round 5: what the line says about walk, loads and stores is the launcher's own record -- fe_last_launch_info)
+    assert line["walk"]["tiles"] == 62500 * (1 if workload == "grad" else 1) and 0 < line["walk"]["static_tiles"] < line["walk"]["tiles"]
+    assert line["loads"]["streamed_operand"].startswith("non-temporal") and line["stores"]["policy"] == "non-temporal"
+    assert line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["elements"] == 1_000_000 and line["per_rank"][0]["kernel_ms"] > 0
+    assert line["ms_per_step_barrier_inclusive"] >= line["ms_per_step"] and line["placement"]["degraded"] in (True, False)
     assert line["config"]["variant"] == "auto"                   # no silent switch of the kernel variant
     if placement == "split":
         rep = line["placement"]
@@ -100,3 +105,4 @@ def test_bench_spawns_its_own_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dist_backend"] == "gloo"
     assert "self-spawned" in line["launcher"] and line["result_finite"] and line["value"] > 0
     assert line["config"]["elements_total"] == 2 * line["config"]["elements_per_gpu"]
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["kernel_ms"] > 0 and r["placement_mode"] == "separate" for r in line["per_rank"])

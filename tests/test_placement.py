@@ -87,6 +87,7 @@ def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
     from feinsum_amd import _hip
 
     E = 1_000_000
+    placement.recycle_trim(0)          # (arrays of earlier tests that wait for reuse: really freed, so that the counts below are this test's)
     before = placement.split_stats(0)
     out = placement.empty((3, E, 35), torch.float64, "cuda:0")
     assert out.shape == (3, E, 35) and out.dtype == torch.float64 and out.is_contiguous() and out.device.index == 0
@@ -135,27 +136,35 @@ def test_split_allocator_arrays_are_ordinary_tensors_with_the_same_results():
     assert placement.split_info(placement.empty((1000, 35), torch.float64, "cuda:0")) == {}
     assert placement.split_info(placement.empty((3, E, 35), torch.float64, "cuda:0", written=False)) == {}
     assert placement.empty((10, 3), torch.float32, "cpu").device.type == "cpu"
-    # the memory returns to the pool with the last view
-    live = placement.split_stats(0)["live_arrays"]
+    # an array whose last view is gone waits for reuse (round 5: no unmap, no device synchronisation on release) ...
+    kept = placement.recycle_stats()["kept"]
     view = out[2]
     del out, res
-    assert placement.split_stats(0)["live_arrays"] == live        # the view keeps the array
+    assert placement.recycle_stats()["kept"] == kept              # the view keeps the array
     del view
-    assert placement.split_stats(0)["live_arrays"] == live - 1
-    del outs, fres
+    assert placement.recycle_stats()["kept"] == kept + 1
+    again = placement.empty((3, E, 35), torch.float64, "cuda:0")  # ... and the next array of that size IS it
+    assert placement.recycle_stats()["reused"] >= 1 and placement.split_info(again)["pieces"] == n
+    del again, outs, fres
+    # ... and the memory returns to the pool when the waiting arrays are trimmed
+    placement.recycle_trim(0)
     after = placement.split_stats(0)
     assert after["live_arrays"] == before["live_arrays"] and after["live_bytes"] == before["live_bytes"]
+    assert placement.recycle_stats()["free_failures"] == 0
     with pytest.raises(f.InvalidParameterError):
         _hip.split_free(12345 * 4096)                             # not an array of the allocator
 
 
 @pytest.mark.gpu
-def test_split_allocator_never_hands_out_an_address_twice():
+def test_split_allocator_never_hands_out_an_address_twice(monkeypatch):
     """ROCm 7.2 keeps translating a re-mapped virtual range to its FIRST physical handle (tools/vmm_remap_test.cpp), so
     the allocator must never re-use an address: allocate / free cycles return distinct pointers, and what is written
-    through a new array is what is read back after the pool has recycled the physical pieces."""
+    through a new array is what is read back after the pool has recycled the physical pieces.  (With the Python-side
+    recycling of whole arrays switched off -- a recycled array keeps its mapping, which is the point of recycling.)"""
     import torch
 
+    monkeypatch.setenv("FEINSUM_SPLIT_RECYCLE_MIB", "0")
+    placement.recycle_trim(0)
     seen = set()
     for cycle in range(6):
         t = placement.empty((40_000_000,), torch.float64, "cuda:0")          # 320 MB: 76 pieces and a tail
@@ -198,3 +207,51 @@ def test_split_reserve_collects_both_classes_for_arrays_allocated_one_after_the_
     if free is not None:
         assert free[1] * placement.split_info(arrays[0])["piece_mib"] * (1 << 20) >= total // 2 - (64 << 20)
     del arrays
+
+
+@pytest.mark.gpu
+def test_evaluate_without_out_dict_recycles_its_outputs():
+    """an ``evaluate()`` that allocates its own outputs must not pay a VMM map, an unmap and a device
+    synchronisation per call.  The output of the previous call, dropped by the caller, is the output of the next one (same
+    address, stream-ordered through an event); results stay right; inside a stream capture the output is torch's."""
+    import torch
+
+    import dg
+    import feinsum_amd as f
+    from feinsum_amd import measure
+
+    E = 400_000
+    expr = dg.grad()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    dev = {n: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[n]), dtype=torch.float64,
+                         device="cuda", generator=g) for n in sorted(expr.all_args)}
+    ref = f.evaluate(expr, 0, dev, transform={"placement": "separate"}, wait=True)["_fe_out"]
+    placement.recycle_trim(0)
+    s0 = placement.recycle_stats()
+    va0 = placement.split_stats(0)["address_space_reserved"]
+    ptrs = set()
+    for k in range(20):
+        out = f.evaluate(expr, 0, dev)["_fe_out"]          # asynchronous; the previous output is dropped here
+        ptrs.add(out.data_ptr())
+        if k % 5 == 4:
+            assert torch.equal(out, ref)
+    torch.cuda.synchronize()
+    s1 = placement.recycle_stats()
+    # (`out` of call k is still alive while call k + 1 allocates: two arrays take turns)
+    assert len(ptrs) <= 2 and s1["reused"] - s0["reused"] >= 18, (ptrs, s0, s1)
+    assert placement.split_stats(0)["address_space_reserved"] - va0 <= 2 * (3 * E * 35 * 8 + (4 << 20))
+    # inside a capture the allocator is not touched
+    q = f.DeviceQueue(0)
+    _, bound, outs = measure._bind(expr, q, dev, None, None)
+    assert bound.output_allocations["_fe_out"] == "split"
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        _, bound_c, outs_c = measure._bind(expr, f.DeviceQueue(0, stream=torch.cuda.current_stream()), dev, None, None)
+        bound_c.launch(int(torch.cuda.current_stream().cuda_stream))
+    assert "capture" in bound_c.output_allocations["_fe_out"]
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs_c[0], ref)
+    del out, outs, outs_c, bound, bound_c, graph
+    placement.recycle_trim(0)
