@@ -35,8 +35,8 @@ EXPORTED_SYMBOLS = (
     "fe_flops_per_element", "fe_time_launches", "fe_einsum_generic", "fe_kernel_resources",
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
-    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds",
-    "fe_set_cu_limit", "fe_set_wide_blocks", "fe_set_phase_priority", "fe_set_phase_priority_p5", "fe_last_launch_info", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
+    "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds", "fe_set_tail_min_rounds",
+    "fe_set_cu_limit", "fe_set_phase_priority_p5", "fe_set_div_interleave", "fe_last_launch_info", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -171,6 +171,8 @@ def load_library() -> C.CDLL:
     lib.fe_split_trim.argtypes = []
     lib.fe_set_tail_rounds.restype = C.c_int
     lib.fe_set_tail_rounds.argtypes = [C.c_int32]
+    lib.fe_set_tail_min_rounds.restype = C.c_int
+    lib.fe_set_tail_min_rounds.argtypes = [C.c_int32]
     lib.fe_set_temporal_loads_mib.restype = C.c_int
     lib.fe_set_temporal_loads_mib.argtypes = [C.c_int32]
     lib.fe_set_write_through_mib.restype = C.c_int
@@ -179,12 +181,10 @@ def load_library() -> C.CDLL:
     lib.fe_set_cu_limit.argtypes = [C.c_int32]
     lib.fe_last_launch_info.restype = C.c_int
     lib.fe_last_launch_info.argtypes = [C.POINTER(C.c_int64), C.c_int32]
-    lib.fe_set_phase_priority.restype = C.c_int64
-    lib.fe_set_phase_priority.argtypes = [C.c_int64]
     lib.fe_set_phase_priority_p5.restype = C.c_int
     lib.fe_set_phase_priority_p5.argtypes = [C.c_int32]
-    lib.fe_set_wide_blocks.restype = C.c_int
-    lib.fe_set_wide_blocks.argtypes = [C.c_int64]
+    lib.fe_set_div_interleave.restype = C.c_int64
+    lib.fe_set_div_interleave.argtypes = [C.c_int64]
     lib.fe_stream_retired.restype = C.c_int
     lib.fe_stream_retired.argtypes = [C.c_void_p]
     lib.fe_tail_plant.restype = C.c_int
@@ -433,6 +433,12 @@ def set_tail_rounds(rounds: int) -> int:
     return int(load_library().fe_set_tail_rounds(int(rounds)))
 
 
+def set_tail_min_rounds(rounds: int) -> int:
+    """Launches of fewer than *rounds* full rounds walk statically (fe_set_tail_min_rounds; default 4); returns the previous
+    setting.  A tuning knob -- results do not depend on it."""
+    return int(load_library().fe_set_tail_min_rounds(int(rounds)))
+
+
 def set_cu_limit(cus: int) -> int:
     """Size the persistent grids as if the device had *cus* compute units (fe_set_cu_limit; 0 = the device's own count);
     returns the previous limit.  Results do not depend on it."""
@@ -505,15 +511,9 @@ def last_launch_info() -> dict:
     d = {k: int(buf[i]) for i, k in enumerate(_LAST_LAUNCH[:n])}
     if not d.get("valid"):
         return {}
-    d["phase_priority"] = bool(d["kind"] & 2)
-    d["kind"] = "sixteen waves per CU" if d["kind"] & 1 else "default"
+    d["interleaved"] = bool(d["kind"] & 4)
+    d["kind"] = "B build interleaved" if d["kind"] & 4 else "default"
     return d
-
-
-def set_phase_priority(tiles: int) -> int:
-    """grad / div launches of at most *tiles* tiles per body run their f64 VALU phases at raised issue priority
-    (fe_set_phase_priority; 0 = never); returns the previous setting.  A tuning knob -- results do not depend on it."""
-    return int(load_library().fe_set_phase_priority(int(tiles)))
 
 
 def set_phase_priority_p5(on: bool) -> bool:
@@ -521,10 +521,10 @@ def set_phase_priority_p5(on: bool) -> bool:
     return bool(load_library().fe_set_phase_priority_p5(1 if on else 0))
 
 
-def set_wide_blocks(tiles: int) -> int:
-    """p = 4 grad / div launches (one field) of at most *tiles* 16-element tiles run on the sixteen-waves-per-CU kernels
-    (fe_set_wide_blocks; 0 = never, 1 = always); returns the previous setting.  A tuning knob."""
-    return int(load_library().fe_set_wide_blocks(int(tiles)))
+def set_div_interleave(tiles: int) -> int:
+    """Short div launches of at most *tiles* tiles run on the interleaved kernel (fe_set_div_interleave; 0 = never); returns the
+    previous setting."""
+    return int(load_library().fe_set_div_interleave(int(tiles)))
 
 
 def set_write_through_mib(mib: int) -> int:

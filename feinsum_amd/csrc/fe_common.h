@@ -103,15 +103,13 @@ constexpr long long kTemporalInputBytes = 248ll << 20;
 // without nt costs 16 % and with nt it is level -- the write-back at the end is a fixed cost that only short launches see.
 constexpr int kOpStoresWriteThrough = 32;
 constexpr long long kWriteThroughOutputBytes = 128ll << 20;
-// kOpPhasePriority (round 5; short launches): a wave's f64 VALU phases -- the B-fragment build of div, the Jacobian contraction
-// ("stage 2") of grad -- run at raised issue priority, its matrix phases at priority 0.  Why: the f64 MFMAs execute on the
-// vector f64 datapath (same peak; profiles/r05/mfma_valu_overlap_with_control.txt), so a partner wave's f64 VALU instruction
-// can only slip in BETWEEN two 64-cycle MFMAs, and the arbiter prefers the older wave's (always ready) next MFMA: per-tile
-// stamps at E = 1e5 show a wave's B build taking 2.3-4.1 us beside its partner's matrix phase against 0.4-0.6 us alone, and
-// grad's stage 2 2.4-3.5 us against 1.0 (profiles/r05/tiles_{grad,div}_100000_before.txt) -- the wave is then late for its own
-// next matrix phase and the pipe idles.  With the VALU phase prioritised it finishes in time and the partner's MFMAs lose only
-// the ~100 issue slots it needs.  (Round 2 measured fixed phase priorities at E = 1e6, where the launch is memory bound and
-// the alternating balance_priority is better: there the flag stays off.)
+// kOpPhasePriority (round 5; the eight-wave p = 5 kernels, opt-in: fe_set_phase_priority_p5): a wave's f64 VALU phases -- the
+// B-fragment build of div, the Jacobian contraction of grad -- at raised issue priority, its matrix phases at priority 0.
+// Measured: p = 5 div -1.0 ... -1.3 % at E >= 1e6, grad -0.8 ... +1.5 % (profiles/r05/p5_phase_priorities_ab.txt).  On the p = 4
+// kernels the same was measured and removed again: grad +4 % at E = 1e5, div -2 ... -3 % (superseded by the interleaved B
+// build of fe_div.h), the fused launches +-1 % (profiles/r05/phase_priorities_ab.txt).  The arbiter itself does not listen to
+// s_setprio where it would matter: beside a partner's pure MFMA stream a wave's VALU instructions take 8.8 cycles each at
+// either priority and the MFMA stream is not slowed (profiles/r05/mfma_arbiter_two_waves.txt).
 constexpr int kOpPhasePriority = 64;
 // One 16-byte write-through store per lane, in the addressing form the compiler gives its own stores (wave-uniform base in
 // SGPRs + one 32-bit lane offset + immediate): with a 64-bit VGPR address per store the same instruction cost 3 - 12 %.

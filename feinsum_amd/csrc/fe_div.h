@@ -119,8 +119,10 @@ struct DivGeom {
 // remainder code.
 // kDyn (plain single-field div of tetrahedra, register fragments): behind two static rounds the tiles come by tickets
 // (fe_common.h, dynamic walk); `tail` = the launch's counters (null: static walk), `t_static` = statically walked tiles.
+// kIlv (round 5; short launches of the plain div, static walk): the B fragments are built k-quad by k-quad BETWEEN the MFMA groups
+// of the same wave instead of all up front -- see the loop.
 template <int NP, int M, int kDbg = 0, int MODE = 0, int ND = 3, bool ALDS = false, bool W8 = false, bool kPrep = false,
-          bool kDyn = false>
+          bool kDyn = false, bool kIlv = false>
 __device__ __forceinline__ void div3d_mfma_body(
     const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep, const FieldPtrs& P,
     int nb, int64_t E, int64_t nTiles, int op_flags, int jes, const unsigned bid, const unsigned nblk,
@@ -132,7 +134,7 @@ __device__ __forceinline__ void div3d_mfma_body(
     // only) = the walk covers both halves of the element range at once, see `phys` below
     const int opT = op_flags & 1;
     const bool tload = (op_flags & kOpLoadsTemporal) != 0;   // the u planes by plain loads (fe_common.h)
-    const bool phase_prio = (op_flags & kOpPhasePriority) != 0;   // short launches: the B build at raised priority (fe_common.h)
+    const bool phase_prio = W8 && (op_flags & kOpPhasePriority) != 0;   // the eight-wave kernels, opt-in (fe_common.h)
     using G = DivGeom<NP, M, MODE, ND, ALDS, W8>;
     using WaveLds = typename G::WaveLds;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -808,9 +810,50 @@ __device__ __forceinline__ void div3d_mfma_body(
     unsigned* const done = tail_pool_reports(counter);
     bool pending = false, reported = false;
     auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
+    // the next unit's tile under the dynamic walk (called once per unit, in front of the next unit's loads and behind the wait for
+    // this unit's: vector-memory ops in issue order [ticket or report] L(next unit) S(this unit))
+    auto resolve_next_tile = [&](int64_t tile_, int fk_, bool next_new_tile_, int64_t& nt_) {
+        if constexpr (kDyn) {
+            if (dyn && nb == 1) {
+                if (pending) {   // asked for one iteration ago, in front of this tile's loads: it is here
+                    const unsigned t = tail_wait<G::STORES, 0>();
+                    nt_ = tail_ticket_tile(t, t_static, pool, tEnd);
+                    pending = false;
+                    if (nt_ < 0) {   // this wave's pool is empty: stop asking, report
+                        tail_request<1>(done);
+                        reported = true;
+                    }
+                } else {
+                    nt_ = static_next(tile_);
+                }
+                if (nt_ >= 0 && static_next(nt_) < 0) {   // the tile after next is not static
+                    tail_request<0>(counter);
+                    pending = true;
+                }
+                if (nt_ < 0) nt_ = tEnd;
+            } else if (dyn) {
+                if (fk_ == 0 && static_next(tile_) < 0) {   // first field of a tile whose successor is not static
+                    tail_request<0>(counter);
+                    pending = true;
+                }
+                if (next_new_tile_) {
+                    if (pending) {   // asked for b - 1 units ago, in front of the second field's loads, which this wave has waited for
+                        nt_ = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, pool, tEnd);
+                        pending = false;
+                        if (nt_ < 0) {
+                            tail_request<1>(done);
+                            reported = true;
+                        }
+                    } else {
+                        nt_ = static_next(tile_);
+                    }
+                    if (nt_ < 0) nt_ = tEnd;
+                }
+            }
+        }
+    };
     while (tile < tEnd) {
-        if (!phase_prio) balance_priority(younger_half, iteration);
-        ++iteration;
+        balance_priority(younger_half, iteration++);
         const int64_t e0 = phys(tile) * G::TEL;
         double* const out = field_out(P, fk);
         const bool next_new_tile = (fk + 1 == nb);
@@ -821,7 +864,97 @@ __device__ __forceinline__ void div3d_mfma_body(
         else wait_vmcnt<G::STORES>();
         first = false;
         FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
-        if (phase_prio) __builtin_amdgcn_s_setprio(3);                           // f64 VALU phase: the B fragments
+        if constexpr (kIlv) {
+            // ---- interleaved form.  The f64 MFMAs run on the vector f64 datapath: beside its partner's matrix phase a wave's
+            //      81 f64 VALU instructions of the B build only get the slots between two 64-cycle MFMAs, and the build takes
+            //      2.3-4.1 us instead of 0.4-0.6 (profiles/r05/tiles_div_100000_before.txt) -- the wave is late for its own matrix
+            //      phase and the pipe idles.  Here the 9 VALU instructions of k-quad jq + 1 follow the 9 MFMAs of k-quad jq in
+            //      the wave's own stream (a wave's own VALU instruction costs its 4-5 cycles behind its own MFMA, no more), so a
+            //      tile is ONE phase of MFMAs and VALU work and the two waves of a SIMD simply share the pipe.  The u planes are
+            //      needed until the last k-quad is built: the next tile's loads go out behind the MFMAs of the last but one.
+            static_assert(MODE == 0 && ND == 3 && M == 1 && !ALDS && !W8 && !kPrep && (kDbg & ~128) == 0, "interleaved B build: plain div of tetrahedra");
+            double jac[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
+            auto read_quad = [&](int jq, double (&ux)[3]) {
+                const int j = 4 * jq + g;
+                const int jc = j < NP ? j : 0;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) ux[x] = j < NP ? L->u[x][tile_index<NP>(n, jc)] : 0.0;
+            };
+            auto build_quad = [&](const double (&ux)[3], double (&bq)[3]) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double v = jac[r] * ux[0];
+#pragma unroll
+                    for (int x = 1; x < 3; ++x) v = __builtin_fma(jac[x * 3 + r], ux[x], v);   // the order of the plain form: same bits
+                    bq[r] = v;
+                }
+            };
+            v4d acc[G::BT > 0 ? G::BT : 1];
+            double accs[G::NS > 0 ? G::NS : 1];
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+            double ux[2][3], bq[2][3];
+            read_quad(0, ux[0]);
+            read_quad(1, ux[1]);
+            build_quad(ux[0], bq[0]);
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq) {
+                const int cur = jq & 1, nxt = cur ^ 1;
+                if (jq + 2 < G::KSJ) read_quad(jq + 2, ux[cur]);     // (ux[cur] was consumed by build_quad of this k-quad)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_big(t, jq, r), bq[cur][r], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16], bq[cur][r], accs[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (jq + 1 < G::KSJ) build_quad(ux[nxt], bq[nxt]);
+                if (jq + 2 == G::KSJ) {   // every u value is in a register: hand the planes back to the DMA engine
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(bq[nxt][r]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    resolve_next_tile(tile, fk, next_new_tile, nt);
+                    if (nt < tEnd) issue_loads(nt, nk, next_new_tile);
+                    FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the last B fragments built, the next unit's loads issued
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
+            double* ob = L->o;
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) ob[tile_index<NP>(n, 16 * t + g + 4 * qq)] = acc[t][qq];
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) {
+                const int i = 16 * G::BT + 4 * q + g;
+                if (16 * G::BT + 4 * q + 3 < NP || i < NP) ob[tile_index<NP>(n, i)] = accs[q];
+            }
+            wave_lds_fence();
+            double* op = out + e0 * NP;
+#pragma unroll
+            for (int c = 0; c < G::SUB_INSTR; ++c) {
+                const int qc = c * 64 + lane;
+                if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
+                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc));
+                    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+            }
+            wave_lds_fence();
+            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
+            ++dbg_it;
+            fk = nk;
+            tile = nt;
+            continue;
+        }
 
         // ---- all B fragments of the tile: Ju[(jq, r)][e = 16m + n], j = 4 jq + g
         double bfrag[M][G::KSJ][G::NBF];
@@ -872,46 +1005,8 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int k = 0; k < ND * ND; ++k) asm volatile("" : "+v"(jkeep[m][k]));
         }
-        if constexpr (kDyn) {
-            if (dyn && nb == 1) {
-                if (pending) {   // asked for one iteration ago, in front of this tile's loads: it is here
-                    const unsigned t = tail_wait<G::STORES, 0>();
-                    nt = tail_ticket_tile(t, t_static, pool, tEnd);
-                    pending = false;
-                    if (nt < 0) {   // this wave's pool is empty: stop asking, report
-                        tail_request<1>(done);
-                        reported = true;
-                    }
-                } else {
-                    nt = static_next(tile);
-                }
-                if (nt >= 0 && static_next(nt) < 0) {   // the tile after next is not static
-                    tail_request<0>(counter);
-                    pending = true;
-                }
-                if (nt < 0) nt = tEnd;
-            } else if (dyn) {
-                if (fk == 0 && static_next(tile) < 0) {   // first field of a tile whose successor is not static
-                    tail_request<0>(counter);
-                    pending = true;
-                }
-                if (next_new_tile) {
-                    if (pending) {   // asked for b - 1 units ago, in front of the second field's loads, which this wave has waited for
-                        nt = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, pool, tEnd);
-                        pending = false;
-                        if (nt < 0) {
-                            tail_request<1>(done);
-                            reported = true;
-                        }
-                    } else {
-                        nt = static_next(tile);
-                    }
-                    if (nt < 0) nt = tEnd;
-                }
-            }
-        }
+        resolve_next_tile(tile, fk, next_new_tile, nt);   // (dynamic walk: the ticket asked for earlier is read here)
         if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
-        if (phase_prio) __builtin_amdgcn_s_setprio(0);                           // matrix phase
         FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // B fragments built, the next unit's loads issued
         if constexpr ((kDbg & 64) != 0 && MODE == 0 && ND == 3 && M == 1) {
             // experiment (kDbg & 64): touch the tile AFTER next -- one dword per 128-byte line of its three planes and nine J rows --
@@ -1083,14 +1178,21 @@ __device__ __forceinline__ void div3d_mfma_body(
     }
 }
 
+// the plain div with the B build interleaved into the matrix phase (kIlv above): short launches, static walk
+template <int NP, int kDbg = 0>
+__global__ __launch_bounds__(256, 2) void div3d_mfma_ilv_kernel(
+    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT) {
+    div3d_mfma_body<NP, 1, kDbg, 0, 3, false, false, false, false, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x);
+}
+
 // the plain single-field div with a dynamic walk (see fe_common.h)
 // (kBatched: see grad3d_mfma_tail_kernel)
-template <int NP, int M, bool kBatched = false>
+template <int NP, int M, bool kBatched = false, bool kIlv = false>
 __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void div3d_mfma_tail_kernel(
     const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT,
     unsigned* __restrict__ tail, int64_t t_static) {
-    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true>(J, D, nullptr, P, kBatched ? nb : 1, E, nTiles, opT, 0, blockIdx.x,
-                                                                gridDim.x, nullptr, tail, t_static);
+    div3d_mfma_body<NP, M, 0, 0, 3, false, false, false, true, kIlv>(J, D, nullptr, P, kBatched ? nb : 1, E, nTiles, opT, 0, blockIdx.x,
+                                                                      gridDim.x, nullptr, tail, t_static);
 }
 
 // triangles (ND = 2) with a dynamic walk: div (MODE 0) and grad by components (MODE 4), any number of fields
@@ -1127,14 +1229,6 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void div3d_mfma_kernel(
     int64_t E, int64_t nTiles, int opT, int jes) {
     div3d_mfma_body<NP, M, kDbg, MODE, ND, ALDS, W8, kPrep>(J, D, prep, P, nb, E, nTiles, opT, jes, blockIdx.x,
                                                             gridDim.x);
-}
-
-// EXPERIMENT (round 5): the eight-wave kernels (A in LDS) at p = 4 with TWO blocks per CU = four waves per SIMD, for short
-// launches: with two waves per SIMD and three tiles per wave the matrix pipe idles whenever both are between MFMA phases
-template <int NP, int MODE>
-__global__ __launch_bounds__(512, 4) void wide_w8_kernel(
-    const double* __restrict__ J, const double* __restrict__ D, FieldPtrs P, int nb, int64_t E, int64_t nTiles, int opT) {
-    div3d_mfma_body<NP, 1, 0, MODE, 3, true, true>(J, D, nullptr, P, nb, E, nTiles, opT, 0, blockIdx.x, gridDim.x);
 }
 
 // grad-type planes at p = 5 (MODE 5): the fields' u pointers travel in P.v, everything else in Q

@@ -35,6 +35,15 @@ __device__ __forceinline__ void body_boundary() {
 template <int A, int B>
 constexpr int cmax() { return A > B ? A : B; }
 
+// The div body of a fused launch.  (Its interleaved form -- fe_div.h, kIlv -- was measured here in round 5 and buys nothing beside
+// a grad body on the same CU: profiles/r05/fused_interleave_ab.txt.)
+template <int NP, int MD, bool kPrep, bool kDyn>
+__device__ __forceinline__ void fused_div_body(const double* __restrict__ J, const double* __restrict__ D, const void* __restrict__ prep,
+                                               const FieldPtrs& Pd, int64_t E, int64_t nTilesD, int op, unsigned* tail_d, int64_t static_d) {
+    div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x, nullptr, tail_d,
+                                                                static_d);
+}
+
 // div then grad, sharing J and D (BASELINE config 3).
 template <int NP, int MG, int MD>
 struct GradDivGeom {
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_ker
     // (Two straight-line sequences, not a loop over the bodies: in a loop the register allocator keeps state of one
     // body alive across the other and spills -- 408 bytes of scratch per lane and 4.7 % more HBM traffic, measured.)
     const bool swap = ((opT & 256) && blockIdx.x >= gridDim.x / 2) || ((opT & 512) && (blockIdx.x & 1));
-    const int op = opT & (1 | kOpLoadsTemporal | kOpPhasePriority);
+    const int op = opT & (1 | kOpLoadsTemporal);
 #ifdef FE_EXPERIMENTS
     if ((opT & 1024) && gridDim.x >= 2 && (gridDim.x & 1) == 0) {
         // ROLE SPLIT (bit 10; experiment build only -- measured in round 3 and 0.5 % slower): the older half of the grid runs div over ALL tiles,
@@ -80,8 +89,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_ker
     }
 #endif
     if (!swap) {
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x,
-                                                                    nullptr, tail_d, ft.static_d);
+        fused_div_body<NP, MD, kPrep, kDyn>(J, D, prep, Pd, E, nTilesD, op, tail_d, ft.static_d);
         body_boundary();
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
                                                        nTilesG, op, blockIdx.x, gridDim.x, tail_g, ft.static_g);
@@ -89,8 +97,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void graddiv3d_mfma_ker
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, D, prepared_grad_section<kPrep>(prep), 1, 3, E,
                                                        nTilesG, op, blockIdx.x, gridDim.x, tail_g, ft.static_g);
         body_boundary();
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(J, D, prep, Pd, 1, E, nTilesD, op, 0, blockIdx.x, gridDim.x,
-                                                                    nullptr, tail_d, ft.static_d);
+        fused_div_body<NP, MD, kPrep, kDyn>(J, D, prep, Pd, E, nTilesD, op, tail_d, ft.static_d);
     }
 }
 
@@ -124,8 +131,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void waveop3d_mfma_kern
     // order 3: the younger half of the grid runs grad before div (see graddiv3d_mfma_kernel); the lift comes last everywhere
     const bool swap = a.order == 3 && blockIdx.x >= gridDim.x / 2;
     if (!swap) {
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, a.load_flags, 0, blockIdx.x,
-                                                                    gridDim.x, nullptr, tail_d, ft.static_d);
+        fused_div_body<NP, MD, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, a.E, a.nTilesD, a.load_flags, tail_d, ft.static_d);
         body_boundary();
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
                                                        a.nTilesG, a.load_flags, blockIdx.x, gridDim.x, tail_g, ft.static_g);
@@ -133,8 +139,7 @@ __global__ __launch_bounds__(256, 2) FE_TAIL_KERNEL_ATTR void waveop3d_mfma_kern
         grad3d_mfma_body<NP, MG, 0, true, kPrep, kDyn>(Pg, a.D, prepared_grad_section<kPrep>(a.prepD), 1, 3, a.E,
                                                        a.nTilesG, a.load_flags, blockIdx.x, gridDim.x, tail_g, ft.static_g);
         body_boundary();
-        div3d_mfma_body<NP, MD, 0, 0, 3, false, false, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, 1, a.E, a.nTilesD, a.load_flags, 0, blockIdx.x,
-                                                                    gridDim.x, nullptr, tail_d, ft.static_d);
+        fused_div_body<NP, MD, kPrep, kDyn>(a.J, a.D, a.prepD, Pd, a.E, a.nTilesD, a.load_flags, tail_d, ft.static_d);
     }
     body_boundary();
     facemass_mfma_body<NP, NFP, MF, NB, kFmNf, false, false, kPrep, kDynF>(a.Jf, a.R, a.prepR, Pf, a.E, a.nTilesF, a.jfe | a.load_flags,

@@ -238,8 +238,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     static_assert(!kDyn || (kPlain && !kPrep), "dynamic walk: plain launches of one field");
     const int opT = op_flags & 1;                                  // operator stored transposed
     const bool tload = (op_flags & kOpLoadsTemporal) != 0;         // the u tiles by plain loads (fe_common.h)
-    const bool wthrough = !kDyn && kPlain && (op_flags & kOpStoresWriteThrough) != 0;   // short launches (static walk): fe_common.h
-    const bool phase_prio = (op_flags & kOpPhasePriority) != 0;                          // short launches: fe_common.h
+    const bool wthrough = kPlain && (op_flags & kOpStoresWriteThrough) != 0;   // short launches: fe_common.h
     const int nx = kPlain ? 3 : nx_;
     using G = GradGeom<NP, M>;
     using WaveLds = typename G::WaveLds;
@@ -367,7 +366,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
     auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt) {
         FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
-        if (phase_prio) __builtin_amdgcn_s_setprio(0);                          // matrix phase
         double* out_x[3];
         out_x[0] = grad_plane_out(P, fk, 0);
         out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
@@ -400,7 +398,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
             }
 
             FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the matrix work is issued
-            if (phase_prio) __builtin_amdgcn_s_setprio(3);                          // f64 VALU phase (kept through the next unit's load issue)
             // ---- stage 2 + transposed store, plane by plane
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
@@ -422,7 +419,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
                 wave_lds_fence();
                 double* op = out_x[x] + (e0 + 16 * m) * NP;
-                if constexpr (!kDyn && kPlain && kDbg == 0) {
+                if constexpr (kPlain && (kDbg & ~32) == 0) {
                     if (wthrough) {   // all values out of LDS first, then the stores back to back (as the compiler orders its own)
                         v2d vals[G::SUB_INSTR];
 #pragma unroll
@@ -493,8 +490,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
             int buf = 0, iteration = 0;
             const bool younger_half = bid >= (nblk + 1) / 2;
             while (cur >= 0) {
-                if (!phase_prio) balance_priority(younger_half, iteration);   // dyn
-                ++iteration;
+                balance_priority(younger_half, iteration++);   // dyn
                 bool extra = false;   // one more vector-memory op (ticket or report) issued in this iteration
                 if (pending) {   // the next tile comes from a ticket: younger than it are L(cur) and S(previous)
                     const unsigned t = first ? tail_wait<0, 0>() : prev_pre ? tail_wait<NS, 0>() : tail_wait<NL + NS, 0>();
@@ -562,8 +558,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     unsigned* const doneb = tail_pool_reports(counterb);
     bool pendingb = false, reportedb = false;
     while (tile < tEnd) {
-        if (!phase_prio) balance_priority(younger_half, iteration);
-        ++iteration;
+        balance_priority(younger_half, iteration++);
         // Vector-memory ops in issue order: L(unit) S(previous unit) [ticket] L(next unit) | wait L(unit).
         // The stores of the previous unit and the loads of the next one are younger than this
         // unit's loads and stay in flight.

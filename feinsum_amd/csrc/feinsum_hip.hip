@@ -325,16 +325,24 @@ unsigned* tail_slot(hipStream_t s, int sets = 1) {
 // grids of fewer than 8 blocks per pool: a block's pool is (bid / 8) % kTailPools and nobody steals, so that a pool
 // without blocks would keep its tiles (a 32-CU partition launches 64 blocks).
 std::atomic<int> g_tail_rounds{[] { const char* e = getenv("FEINSUM_TAIL_ROUNDS"); return e ? atoi(e) : (1 << 20); }()};
-int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock) {
+// (experiments: FEINSUM_TAIL_MIN_ROUNDS lowers the four-round rule below, to re-measure tickets in shorter launches)
+std::atomic<int> g_tail_min_rounds_v{[] { const char* e = getenv("FEINSUM_TAIL_MIN_ROUNDS"); return e ? atoi(e) : 4; }()};
+#define g_tail_min_rounds g_tail_min_rounds_v.load(std::memory_order_relaxed)
+// `fused`: a body of a fused launch (div + grad, div + grad + lift) walks dynamically from THREE rounds on -- the bodies of a block
+// follow each other, so a block that is late in one body starts the next late, and tickets absorb that: div + grad at E = 1e5
+// 46.1 -> 43.4 us, the pipeline 103.9 -> 97.5, -1 ... -6 % at every size between three and four and a half rounds, level at exact
+// multiples (profiles/r05/fused_tickets3_ab.txt); single launches lose up to 8 % there (single_tickets3_ab.txt) and keep four.
+int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock, bool fused = false) {
     const int dyn_rounds = g_tail_rounds.load(std::memory_order_relaxed);
     const int64_t waves = blocks * wavesPerBlock;
     const int64_t rounds = waves > 0 ? nTiles / waves : 0;
+    const int min_rounds = (fused && g_tail_min_rounds == 4) ? 3 : g_tail_min_rounds;
     if (blocks < 8 * fe::kTailPools) return nTiles;
-    if (dyn_rounds < 0 || rounds < 4 || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
+    if (dyn_rounds < 0 || rounds < min_rounds || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
     // four rounds and a bit: tickets pay once the partial fifth round is at least half a round -- a static walk leaves those waves
     // a tile behind the rest (div E = 163 000: 41.2 -> 37.7 us; grad 150 000: 34.4 -> 33.5), while four EXACT rounds are perfectly
     // balanced as they are (grad 131 072: 28.6 static, 30.7 with tickets; profiles/r04/dynamic_walk_from_four_and_a_half_rounds.txt)
-    if (rounds == 4 && (nTiles - 4 * waves) * 2 < waves) return nTiles;
+    if (rounds == 4 && min_rounds == 4 && (nTiles - 4 * waves) * 2 < waves) return nTiles;
     int64_t ks = rounds - dyn_rounds;
     if (ks < 2) ks = 2;
     return ks * waves;
@@ -366,15 +374,16 @@ int write_through_flag(int64_t output_bytes) {
     return output_bytes <= g_write_through_output_bytes.load(std::memory_order_relaxed) ? fe::kOpStoresWriteThrough : 0;
 }
 
-// kOpPhasePriority (fe_common.h) for a launch of `nTiles` tiles per body: launches of at most so many tiles
-// ($FEINSUM_PHASE_PRIORITY_TILES / fe_set_phase_priority; 0 = never)
-std::atomic<long long> g_phase_priority_tiles{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_TILES"); return e ? atoll(e) : 0ll; }()};
+// short div launches (static walk) on the kernel whose B build is interleaved into the matrix phase (fe_div.h, kIlv): launches of
+// at most so many tiles ($FEINSUM_DIV_INTERLEAVE_TILES / fe_set_div_interleave; 0 = never)
+// Measured (profiles/r05/div_interleave_ab.txt, div_interleave_small.txt; same arrays, in-process): -3 ... -6 % at E = 8e4 ... 3e5 under
+// either walk, -2 % at 4e5, level from 6e5 on (the launch is memory bound there) -- hence the default of 37 500 tiles (E = 6e5).
+constexpr long long kDivInterleaveTiles = 37500;
+std::atomic<long long> g_div_interleave_tiles{[] { const char* e = getenv("FEINSUM_DIV_INTERLEAVE_TILES"); return e ? atoll(e) : kDivInterleaveTiles; }()};
+
 // the same flag for the eight-wave p = 5 kernels (compute bound at every size): $FEINSUM_PHASE_PRIORITY_P5 / fe_set_phase_priority_p5
 std::atomic<int> g_phase_priority_p5{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_P5"); return e ? atoi(e) : 0; }()};
 int phase_priority_flag_p5() { return g_phase_priority_p5.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0; }
-int phase_priority_flag(int64_t nTiles) {
-    return nTiles <= g_phase_priority_tiles.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0;
-}
 
 // What the launcher decided for the MFMA launch enqueued last by this thread (fe_last_launch_info): bench.py and the tools report
 // these instead of re-deriving the rules (round 4's report recomputed them in Python and could disagree with the kernel).
@@ -388,10 +397,10 @@ void note_launch(bool dynamic, int flags, unsigned blocks, int waves_per_block, 
     L.valid = 1;
     L.dynamic_walk = dynamic ? 1 : 0;
     L.temporal_loads = (flags & fe::kOpLoadsTemporal) ? 1 : 0;
-    L.write_through = (!dynamic && (flags & fe::kOpStoresWriteThrough)) ? 1 : 0;
+    L.write_through = (flags & fe::kOpStoresWriteThrough) ? 1 : 0;
     L.blocks = (int)blocks;
     L.waves_per_block = waves_per_block;
-    L.kind = kind | ((flags & fe::kOpPhasePriority) ? 2 : 0);
+    L.kind = kind;
     L.bodies = bodies;
     L.tiles = tiles;
     L.static_tiles = dynamic ? static_tiles : tiles;
@@ -537,33 +546,6 @@ int launch_div_p5(const double* J, const double* D, const fe::FieldPtrs& P, int 
     return FE_OK;
 }
 
-// EXPERIMENT (round 5): p = 4 grad / div on the eight-wave kernels (A in LDS), two blocks per CU = four waves per SIMD
-// (FEINSUM_WIDE_BLOCKS / fe_set_wide_blocks: 0 never, 1 always, N > 1: launches of at most N tiles)
-std::atomic<long long> g_wide_blocks{[] { const char* e = getenv("FEINSUM_WIDE_BLOCKS"); return e ? atoll(e) : 0ll; }()};
-bool wide_blocks_wanted(int64_t nTiles) {
-    const long long w = g_wide_blocks.load(std::memory_order_relaxed);
-    return w == 1 || (w > 1 && nTiles <= w);
-}
-template <int NP, int MODE>
-int launch_wide(const double* J, const double* D, const fe::FieldPtrs& P, int nb, int64_t E, int opT, hipStream_t s,
-                int64_t* e_done) {
-    using G = fe::DivGeom<NP, 1, MODE, 3, true, true>;
-    static_assert(2 * G::LDS_BYTES <= 160 * 1024, "two eight-wave blocks per CU");
-    const int64_t nTiles = E / G::TEL;
-    *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
-    if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + (MODE == 0 ? 3 : 1) * (int64_t)nb * NP) * E * 8);
-    static PerDeviceOnce once;
-    if (int rc = configured(once, fe::wide_w8_kernel<NP, MODE>, MODE == 4 ? "grad p4, eight-wave blocks x 2 per CU" : "div p4, eight-wave blocks x 2 per CU",
-                            G::LDS_BYTES, G::THREADS, 2))
-        return rc;
-    const int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES, cap = 2 * (int64_t)device_cu_count();
-    hipLaunchKernelGGL((fe::wide_w8_kernel<NP, MODE>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(G::THREADS), G::LDS_BYTES, s, J, D, P,
-                       nb, E, nTiles, opT);
-    note_launch(false, opT, (unsigned)(blocks < cap ? blocks : cap), G::WAVES, nTiles, nTiles, 1);
-    return FE_OK;
-}
-
 // ---- the LDS-tiled VALU kernel (fe_tiled.h): any shape whose operator fits in LDS
 constexpr int64_t kTiledMaxLds = fe::kTiledLdsBudget;
 
@@ -629,7 +611,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
     const int64_t nTiles = E / G::TEL;   // full wave tiles; the remainder goes to the generic kernel
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + (int64_t)nb * NP) * E * 8) | phase_priority_flag(nTiles);
+    opT |= temporal_flag((9 + (int64_t)nb * NP) * E * 8);
     static PerDeviceOnce once_plain, once_prepared, once_planes;
     char what[64];
     const void* gsec = prep ? static_cast<const char*>(prep) + fe::kPrepGradOff : nullptr;
@@ -728,6 +710,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                         if (nb == 1) {
                             snprintf(what, sizeof(what), "grad Np=%d M=%d, dynamic walk", NP, M);
                             if (int rc = configured(once_tail, fe::grad3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, 2)) return rc;
+                            opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (short launches: the same rule as the static walk)
                             hipLaunchKernelGGL((fe::grad3d_mfma_tail_kernel<NP, M>), g, b, G::LDS_BYTES, s, P, D, nb, E, nTiles, opT, tail, t_static);
                             note_launch(true, opT, g.x, G::WAVES, nTiles, t_static);
                             break;
@@ -761,7 +744,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv) | phase_priority_flag(nTiles);
+    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv);
     static PerDeviceOnce once_plain, once_prepared;
     char what[64];
     int attr_rc;
@@ -800,7 +783,15 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
         case 8: FE_DIV_CASE(8); break;
         case 32: FE_DIV_CASE(32); break;   // one u plane loaded instead of three (timing only)
         case 64: FE_DIV_CASE(64); break;   // the tile after next touched line by line (L2 prefetch)
-        case 128:                          // per-wave, per-tile time stamps (fe_dbg_tile)
+        case 128:                          // per-wave, per-tile time stamps (fe_dbg_tile); FE_DIV_ILV=1: of the interleaved kernel
+            if constexpr (NP == 35 && M == 1) {
+                if (getenv("FE_DIV_ILV")) {
+                    static PerDeviceOnce once_ilv_dbg;
+                    once_ilv_dbg.run([] { return configure_kernel(fe::div3d_mfma_ilv_kernel<NP, 128>, "experiment", G::LDS_BYTES + fe::kDbgTileLdsBytes, 256, 1); });
+                    hipLaunchKernelGGL((fe::div3d_mfma_ilv_kernel<NP, 128>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, J, D, P, nb, E, nTiles, opT);
+                    break;
+                }
+            }
             hipLaunchKernelGGL((fe::div3d_mfma_kernel<NP, M, 128>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, J, D, nullptr, P, nb, E, nTiles, opT, 0);
             break;
 #endif
@@ -810,12 +801,33 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                                    prep, P, nb, E, nTiles, opT, 0);
                 break;
             }
+            if constexpr (NP == 35 && M == 1) {
+                if (!(opT & fe::kDivWalkSplit) && nTiles <= g_div_interleave_tiles.load(std::memory_order_relaxed) &&
+                    tail_static_tiles(nTiles, g.x, G::WAVES) == nTiles) {   // a short launch (static walk): the interleaved form
+                    static PerDeviceOnce once_ilv;
+                    if (int rc = configured(once_ilv, fe::div3d_mfma_ilv_kernel<NP>, "div Np=35, B build interleaved", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                    hipLaunchKernelGGL((fe::div3d_mfma_ilv_kernel<NP>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT);
+                    note_launch(false, opT & ~fe::kOpStoresWriteThrough, g.x, G::WAVES, nTiles, nTiles, 4);
+                    break;
+                }
+            }
             {
                 if (!(opT & fe::kDivWalkSplit)) {   // behind two static rounds the tiles come by tickets (fe_common.h); any number of fields
                     const int64_t t_static = tail_static_tiles(nTiles, g.x, G::WAVES);
                     unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
                     if (tail) {
                         static PerDeviceOnce once_tail;
+                        if constexpr (NP == 35 && M == 1) {
+                            if (nb == 1 && nTiles <= g_div_interleave_tiles.load(std::memory_order_relaxed)) {   // the interleaved form, dynamic walk
+                                static PerDeviceOnce once_tail_ilv;
+                                if (int rc = configured(once_tail_ilv, fe::div3d_mfma_tail_kernel<NP, M, false, true>, "div Np=35, B build interleaved, dynamic walk",
+                                                        G::LDS_BYTES, 256, G::BLOCKS_PER_CU))
+                                    return rc;
+                                hipLaunchKernelGGL((fe::div3d_mfma_tail_kernel<NP, M, false, true>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT, tail, t_static);
+                                note_launch(true, opT, g.x, G::WAVES, nTiles, t_static, 4);
+                                break;
+                            }
+                        }
                         if (nb == 1) {
                             snprintf(what, sizeof(what), "div Np=%d M=%d, dynamic walk", NP, M);
                             if (int rc = configured(once_tail, fe::div3d_mfma_tail_kernel<NP, M>, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
@@ -1032,9 +1044,7 @@ int grad_fields_launch(const fe::GradFields& P, const double* Jfull, const doubl
 #endif
         int rc = FE_OK;
         switch (Np) {   // wave tile = 16 M elements
-            case 35:
-                if (Jfull && nb == 1 && !prep && dbg == 0 && wide_blocks_wanted(E / 16)) { rc = launch_wide<35, 4>(Jfull, D, Pt, nb, E, opT, s, &e_done); break; }
-                rc = launch_grad<35, 1>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
+            case 35: rc = launch_grad<35, 1>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             case 20: rc = launch_grad<20, 2>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             case 10: rc = launch_grad<10, 3>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
             default: rc = launch_grad<4, 5>(P, Jfull != nullptr, D, prep, nb, nx, E, dbg, opT, s, &e_done); break;
@@ -1089,13 +1099,13 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     const unsigned grid = persistent_grid(nTiles, 4);
     fe::FusedTail ft = {nullptr, nTilesD, nTilesG, 0};
     if (kDyn && !prep) {
-        ft.static_d = tail_static_tiles(nTilesD, grid, 4);
-        ft.static_g = tail_static_tiles(nTilesG, grid, 4);
+        ft.static_d = tail_static_tiles(nTilesD, grid, 4, true);
+        ft.static_g = tail_static_tiles(nTilesG, grid, 4, true);
         if (ft.static_d < nTilesD || ft.static_g < nTilesG) ft.tail = tail_slot(s, 2);
     }
     // body order (fe_fused.h): with the static walk the younger half of the grid runs grad first; with tickets every block
     // runs div, then grad (profiles/r03/dynamic_walk_fused.txt: 77.9 - 78.1 against 76.9 - 77.6 %)
-    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8) | phase_priority_flag(nTiles);
+    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8);
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
 #endif
@@ -1131,13 +1141,13 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
     const unsigned grid = persistent_grid(nTiles, 4);
     fe::FusedTail ft = {nullptr, a.nTilesD, a.nTilesG, a.nTilesF};
     if (kDyn && !(a.prepD && a.prepR)) {
-        ft.static_d = tail_static_tiles(a.nTilesD, grid, 4);
-        ft.static_g = tail_static_tiles(a.nTilesG, grid, 4);
-        ft.static_f = NB >= 3 ? tail_static_tiles(a.nTilesF, grid, 4) : a.nTilesF;
+        ft.static_d = tail_static_tiles(a.nTilesD, grid, 4, true);
+        ft.static_g = tail_static_tiles(a.nTilesG, grid, 4, true);
+        ft.static_f = NB >= 3 ? tail_static_tiles(a.nTilesF, grid, 4, true) : a.nTilesF;
         if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
     }
     fe::WaveOpArgs args = a;
-    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8) | phase_priority_flag(nTiles);
+    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8);
     if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);
@@ -1627,9 +1637,7 @@ int fe_div3d_prepared_f64(const double* J, const double* D, const void* D_prepar
         int rc = FE_OK;
         const int opf = opT | (split_walk ? fe::kDivWalkSplit : 0);
         switch (Np) {   // wave tile = 16 M elements
-            case 35:
-                if (b == 1 && !prep && dbg == 0 && !split_walk && wide_blocks_wanted(E / 16)) { rc = launch_wide<35, 0>(J, D, P, b, E, opT, s, &e_done); break; }
-                rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
+            case 35: rc = launch_div<35, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             case 20: rc = launch_div<20, 1>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             case 10: rc = launch_div<10, 3>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
             default: rc = launch_div<4, 5>(J, D, prep, P, b, E, dbg, opf, s, &e_done); break;
@@ -2175,16 +2183,16 @@ int fe_last_launch_info(int64_t* out, int32_t n) {
     return n < FE_LAST_LAUNCH_INFO ? n : FE_LAST_LAUNCH_INFO;
 }
 
+int fe_set_tail_min_rounds(int32_t rounds) {
+    return g_tail_min_rounds_v.exchange(rounds < 2 ? 2 : rounds);
+}
+
+int64_t fe_set_div_interleave(int64_t tiles) {
+    return g_div_interleave_tiles.exchange(tiles < 0 ? 0 : tiles);
+}
+
 int fe_set_phase_priority_p5(int32_t on) {
     return g_phase_priority_p5.exchange(on ? 1 : 0);
-}
-
-int64_t fe_set_phase_priority(int64_t tiles) {
-    return g_phase_priority_tiles.exchange(tiles < 0 ? 0 : tiles);
-}
-
-int fe_set_wide_blocks(int64_t tiles) {
-    return (int)g_wide_blocks.exchange(tiles < 0 ? 0 : tiles);
 }
 
 int fe_set_cu_limit(int32_t cus) {

@@ -383,6 +383,9 @@ int fe_launch_f32(int32_t family, const fe_argpack* args, void* stream);
  * process (default: all, or the environment's FEINSUM_TAIL_ROUNDS; negative = static walk) and returns the previous value.
  * A tuning knob: results do not depend on it (every tile's arithmetic is position independent). */
 int fe_set_tail_rounds(int32_t rounds);
+/* Launches of fewer than `rounds` full rounds of tiles walk statically (default 4, with the four-and-a-half-rounds rule of
+ * DESIGN.md section 3f; also FEINSUM_TAIL_MIN_ROUNDS; at least 2).  Returns the previous setting.  A tuning knob. */
+int fe_set_tail_min_rounds(int32_t rounds);
 
 /* Who owns ticket counters (the re-entrancy contract of SURVEY 8(b): no launch shares mutable state with a launch that can
  * run beside it).  A launch's counters are zero before and after it, so only launches the device serialises share them:
@@ -444,24 +447,20 @@ int fe_set_write_through_mib(int32_t mib);
 
 /* What the launcher decided for the MFMA launch this THREAD enqueued last (p = 1..4 grad / div / face-mass and the fused
  * launches; other paths leave it unchanged): out[0..n) = {valid, dynamic walk (tickets behind the static rounds), plain
- * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 0: sixteen waves
- * per CU; bit 1: phase priorities), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
+ * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 2: div with the
+ * interleaved B build), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
  * written.  For reports (bench.py prints these instead of re-deriving the launcher's rules). */
 #define FE_LAST_LAUNCH_INFO 10
 int fe_last_launch_info(int64_t* out, int32_t n);
 
-/* Phase priorities in short launches: p = 1..4 grad / div launches (and the fused launches' grad / div bodies) of at most
- * `tiles` 16 M-element tiles per body run their f64 VALU phases (div: the B-fragment build; grad: the Jacobian contraction) at
- * raised issue priority and their matrix phases at priority 0 (0 = never; also FEINSUM_PHASE_PRIORITY_TILES).  Returns the
- * previous setting.  Results do not depend on it. */
-int64_t fe_set_phase_priority(int64_t tiles);
-/* ... and the same for the eight-wave kernels of tetrahedra p = 5 (grad, div), at every size (FEINSUM_PHASE_PRIORITY_P5). */
+/* div launches (p = 4, one field; static or dynamic walk) of at most `tiles` tiles run on the kernel that builds its B fragments
+ * k-quad by k-quad between the MFMA groups of the same wave (default 37500 = E 6e5: -3 ... -6 % at E = 8e4 ... 3e5, level above;
+ * 0 = never; also FEINSUM_DIV_INTERLEAVE_TILES).  Returns the previous setting.  Bitwise the results of the plain kernel. */
+int64_t fe_set_div_interleave(int64_t tiles);
+/* Phase priorities in the eight-wave kernels of tetrahedra p = 5 (grad, div): the waves' f64 VALU phases at raised issue
+ * priority, their matrix phases at priority 0 (default off: -1 % for div at E >= 1e6, +-1 % for grad; also
+ * FEINSUM_PHASE_PRIORITY_P5).  Returns the previous setting.  Results do not depend on it. */
 int fe_set_phase_priority_p5(int32_t on);
-
-/* Short launches of p = 4 grad / div (one field) on the sixteen-waves-per-CU kernels (operator fragments in LDS, two
- * eight-wave blocks per CU): launches of at most `tiles` 16-element tiles (0 = never, 1 = always; also FEINSUM_WIDE_BLOCKS).
- * Returns the previous setting.  Results agree with the default kernels to rounding (another summation order of r). */
-int fe_set_wide_blocks(int64_t tiles);
 
 /* Size the persistent grids as if the device had `cus` compute units (0 = what the device reports; also
  * FEINSUM_CU_LIMIT).  MI355X partitions report 32 (CPX) or 64 (QPX) CUs: grids of fewer than 128 blocks walk statically

@@ -903,3 +903,44 @@ def test_dynamic_walk_of_the_other_kernels(torch_cuda, name, Np, Nfp):
     finally:
         _hip.set_tail_rounds(before)
     assert _hip.tail_check()["dirty_words"] == 0
+
+
+@pytest.mark.parametrize("name", ["div", "div_t", "batched_div3"])
+@pytest.mark.parametrize("E", [16, 100, 1000, 4099, 10007, 98304, 100000, 131072, 300007])
+def test_div_with_the_interleaved_b_build(torch_cuda, name, E):
+    """Round 5: div launches of up to 6e5 elements run on the kernel that builds its B fragments k-quad by k-quad between the
+    MFMA groups of the same wave (fe_div.h, kIlv; the default since round 5: fe_set_div_interleave).  Against the oracle at
+    the sizes the reference's own regime covers (E = 98 304, 100 000, 131 072: src/feinsum/measure.py:202) and BITWISE the plain
+    kernel -- the arithmetic of a tile is the same instruction sequence, only its place in the stream differs -- under the
+    static walk (up to 131 072) and the dynamic one (300 007: ragged too), single and batched."""
+    torch = torch_cuda
+    expr = {"div": dg.div, "div_t": dg.div_t, "batched_div3": lambda: dg.batched_div(3)}[name]()
+    host = generate_host_input_arrays(expr, E, np_seed=E + 3)
+    before = _hip.set_div_interleave(1 << 40)
+    try:
+        got = _run(torch, expr, host)
+        info = _hip.last_launch_info()
+        _hip.set_div_interleave(0)
+        plain = _run(torch, expr, host)
+        info_plain = _hip.last_launch_info()
+    finally:
+        _hip.set_div_interleave(before)
+    assert before == 37500                                    # the default: launches of up to 6e5 elements
+    if name != "batched_div3" or E <= 131072:                 # (batched launches take it under the static walk only)
+        assert info["interleaved"] and not info_plain["interleaved"], (info, info_plain)
+    for k in got:
+        assert np.array_equal(got[k], plain[k]), (name, E, k)
+    if E <= 10007:
+        _assert_close(got, _oracle(expr, host))
+    else:                                                      # sampled oracle slices at the large sizes
+        rng = np.random.default_rng(E)
+        idx = np.sort(rng.choice(E, size=256, replace=False))
+        sub = {}
+        for a in sorted(expr.all_args):
+            shape = expr.arg_to_shape[a]
+            ax = [i for i, d in enumerate(shape) if isinstance(d, f.SizeParam)]
+            sub[a] = np.take(host[a], idx, axis=ax[0]) if ax else host[a]
+        ref = _oracle(expr, sub)
+        for k in got:
+            ax = [i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
+            _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})

@@ -228,18 +228,19 @@ def test_evaluate_without_out_dict_recycles_its_outputs():
     ref = f.evaluate(expr, 0, dev, transform={"placement": "separate"}, wait=True)["_fe_out"]
     placement.recycle_trim(0)
     s0 = placement.recycle_stats()
-    va0 = placement.split_stats(0)["address_space_reserved"]
     ptrs = set()
     for k in range(20):
         out = f.evaluate(expr, 0, dev)["_fe_out"]          # asynchronous; the previous output is dropped here
         ptrs.add(out.data_ptr())
         if k % 5 == 4:
             assert torch.equal(out, ref)
+        if k == 4:                                         # (the first calls map their two arrays and the pool's groups)
+            va_early = placement.split_stats(0)["address_space_reserved"]
     torch.cuda.synchronize()
     s1 = placement.recycle_stats()
     # (`out` of call k is still alive while call k + 1 allocates: two arrays take turns)
     assert len(ptrs) <= 2 and s1["reused"] - s0["reused"] >= 18, (ptrs, s0, s1)
-    assert placement.split_stats(0)["address_space_reserved"] - va0 <= 2 * (3 * E * 35 * 8 + (4 << 20))
+    assert placement.split_stats(0)["address_space_reserved"] == va_early      # no address space per call any more
     # inside a capture the allocator is not touched
     q = f.DeviceQueue(0)
     _, bound, outs = measure._bind(expr, q, dev, None, None)

@@ -1,9 +1,12 @@
 #!/usr/bin/env python
 """
-A/B in one process on the SAME arrays: phase priorities (fe_set_phase_priority: a wave's f64 VALU phases at raised issue
-priority, its matrix phases at priority 0) against the default alternating priority balance.
+A/B in one process on the SAME arrays of a launcher knob against its off state (round 5's knob=phase -- phase priorities on the
+p = 4 kernels -- was measured with this tool and removed: profiles/r05/phase_priorities_ab.txt).
 
-    python tools/phase_ab.py [grad div graddiv pipeline] [E ...]
+    python tools/phase_ab.py [grad div graddiv pipeline] [E ...] [knob=ilv|tickets3|tickets2] [ilv=on]
+
+knob=ilv: div launches on the kernel whose B build is interleaved into the matrix phase (fe_set_div_interleave) instead;
+knob=tickets3 / tickets2: the dynamic walk from three / two full rounds on (fe_set_tail_min_rounds); ilv=on: with the interleaved div.
 """
 import sys
 from pathlib import Path
@@ -17,8 +20,15 @@ import feinsum_amd as f  # noqa: E402
 from feinsum_amd import _hip, measure  # noqa: E402
 
 ALL = ("grad", "div", "graddiv", "pipeline")
-names = [a for a in sys.argv[1:] if a in ALL] or list(ALL)
-sizes = [int(float(a)) for a in sys.argv[1:] if a not in ALL] or [20_000, 50_000, 98_304, 100_000, 131_072, 200_000, 400_000, 1_000_000]
+knob = ([a.split("=")[1] for a in sys.argv[1:] if a.startswith("knob=")] or ["ilv"])[0]
+setter = {"ilv": _hip.set_div_interleave,
+          "tickets3": lambda v: _hip.set_tail_min_rounds(3 if v else 4), "tickets2": lambda v: _hip.set_tail_min_rounds(2 if v else 4)}[knob]
+label = {"ilv": "interleaved B build", "tickets3": "tickets from three rounds", "tickets2": "tickets from two rounds"}[knob]
+if "ilv=on" in sys.argv:       # (other knobs measured with the interleaved div in place)
+    _hip.set_div_interleave(1 << 40)
+args = [a for a in sys.argv[1:] if not a.startswith("knob=") and a != "ilv=on"]
+names = [a for a in args if a in ALL] or list(ALL)
+sizes = [int(float(a)) for a in args if a not in ALL] or [20_000, 50_000, 98_304, 100_000, 131_072, 200_000, 400_000, 1_000_000]
 
 
 def stages_of(what, E):
@@ -51,25 +61,25 @@ for what in names:
         outs = [measure.generate_out_arrays(0, e, E, split=True) for e, _ in stages]
         op = f.bind_operator(stages, 0, out_dicts=outs)
         n = max(20, min(400, int(4e7 / E)))
-        _hip.set_phase_priority(0)
+        setter(0)
         timed(op, 5 * n)   # settle
         best = {0: 1e9, 1: 1e9}
         for rep in range(3):
             for mode in (0, 1):
-                _hip.set_phase_priority((1 << 40) if mode else 0)
+                setter((1 << 40) if mode else 0)
                 best[mode] = min(best[mode], timed(op, n))
-        _hip.set_phase_priority(0)
+        setter(0)
         op.launch(); torch.cuda.synchronize()
         ref = [{k: v.clone() for k, v in od.items()} for od in outs]
         for od in outs:
             for v in od.values():
                 v.fill_(float("nan"))
-        _hip.set_phase_priority(1 << 40)
+        setter(1 << 40)
         op.launch(); torch.cuda.synchronize()
         info = _hip.last_launch_info()
-        _hip.set_phase_priority(0)
+        setter(0)
         same = all(torch.equal(od[k], rd[k]) for od, rd in zip(outs, ref) for k in od)
         a, b = best[0], best[1]
-        print(f"{what:8s} E={E:8d}: default {a * 1e6:7.2f} us = {nbytes / a / 8e12:.3f}   phase priorities {b * 1e6:7.2f} us = {nbytes / b / 8e12:.3f}   "
-              f"({(b / a - 1) * 100:+.1f} %)   same bits {same}   [{'dynamic' if info.get('dynamic_walk') else 'static'} walk, flag {info.get('phase_priority')}]", flush=True)
+        print(f"{what:8s} E={E:8d}: default {a * 1e6:7.2f} us = {nbytes / a / 8e12:.3f}   {label} {b * 1e6:7.2f} us = {nbytes / b / 8e12:.3f}   "
+              f"({(b / a - 1) * 100:+.1f} %)   same bits {same}   [{'dynamic' if info.get('dynamic_walk') else 'static'} walk, {info.get('kind')}]", flush=True)
         del op, outs, ref, stages

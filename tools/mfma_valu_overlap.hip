@@ -50,6 +50,7 @@ typedef short v8s __attribute__((ext_vector_type(8)));
 __device__ unsigned long long result[16];
 
 // KIND 0: f64 FMA, 1: f32 FMA, 2: u32 add, 3: ds_read_b64, 4: f64 FMA as ONE dependent chain
+// second_wave_mode: 0 idle, 1 side work, 2 side work at s_setprio 3; bit 4: the MFMA waves issue NO side work (pure MFMA stream)
 template <int N, int KIND, bool MFMA>
 __global__ __launch_bounds__(512) void probe(double* sink, int iters, int second_wave_mode) {
     __shared__ double lds[4096];
@@ -79,16 +80,26 @@ __global__ __launch_bounds__(512) void probe(double* sink, int iters, int second
         if (KIND == 3 || KIND == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const bool pure = (second_wave_mode & 16) != 0;
     if (mfma_wave) {
-        for (int it = 0; it < iters; ++it) {   // three accumulators in turn: an MFMA never waits for its predecessor's result
-            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc0) : "v"(ma), "v"(mb));
-            side();
-            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc1) : "v"(ma), "v"(mb));
-            side();
-            if (MFMA) asm volatile(MFMA_ASM : "+v"(acc2) : "v"(ma), "v"(mb));
-            side();
+        if (pure) {
+            for (int it = 0; it < iters; ++it) {
+                asm volatile(MFMA_ASM : "+v"(acc0) : "v"(ma), "v"(mb));
+                asm volatile(MFMA_ASM : "+v"(acc1) : "v"(ma), "v"(mb));
+                asm volatile(MFMA_ASM : "+v"(acc2) : "v"(ma), "v"(mb));
+            }
+        } else {
+            for (int it = 0; it < iters; ++it) {   // three accumulators in turn: an MFMA never waits for its predecessor's result
+                if (MFMA) asm volatile(MFMA_ASM : "+v"(acc0) : "v"(ma), "v"(mb));
+                side();
+                if (MFMA) asm volatile(MFMA_ASM : "+v"(acc1) : "v"(ma), "v"(mb));
+                side();
+                if (MFMA) asm volatile(MFMA_ASM : "+v"(acc2) : "v"(ma), "v"(mb));
+                side();
+            }
         }
-    } else if (second_wave_mode) {
+    } else if (second_wave_mode & 3) {
+        if ((second_wave_mode & 3) == 2) __builtin_amdgcn_s_setprio(3);
         for (int it = 0; it < iters; ++it) { side(); side(); side(); }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -132,6 +143,23 @@ int run2(const char* what, double* sink) {
     return 0;
 }
 
+// two waves per SIMD: wave A = a PURE MFMA stream, wave B = N side instructions per A-MFMA-slot, at priority 0 and 3: how the
+// arbiter shares the SIMD between one wave's matrix phase and its partner's VALU phase (both loops run `iters` iterations:
+// the one that finishes first leaves the other alone, so read the LARGER figure as "beside the partner" only when both are close)
+template <int N, int KIND>
+int run3(const char* what, double* sink) {
+    const int iters = 4000;
+    unsigned long long r[2];
+    for (int mode : {17, 18}) {
+        hipLaunchKernelGGL((probe<N, KIND, true>), dim3(256), dim3(512), 0, 0, sink, iters, mode);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(r, HIP_SYMBOL(result), sizeof r));
+        printf("%-28s N = %2d, B at priority %d: wave A (pure MFMA) %6.1f cycles per MFMA, wave B (side only) %6.1f cycles per group of N = %5.1f per instruction\n", what, N,
+               mode == 18 ? 3 : 0, (double)r[0] / iters / 3.0, (double)r[1] / iters / 3.0, (double)r[1] / iters / 3.0 / N);
+    }
+    return 0;
+}
+
 int main() {
     double* sink;
     CK(hipMalloc(&sink, 64));
@@ -148,5 +176,8 @@ int main() {
     printf("# two waves per SIMD: wave A = MFMA + N side instructions, wave B = N side instructions only\n");
     run2<8, 0>("v_fma_f64 (independent)", sink); run2<16, 0>("v_fma_f64 (independent)", sink);
     run2<16, 1>("v_fma_f32", sink); run2<16, 2>("v_add_u32", sink); run2<8, 3>("ds_read_b64 + wait", sink);
+    printf("# two waves per SIMD: wave A = pure MFMA stream, wave B = side work only, at priority 0 / 3\n");
+    run3<4, 0>("v_fma_f64 (independent)", sink); run3<16, 0>("v_fma_f64 (independent)", sink);
+    run3<16, 1>("v_fma_f32", sink); run3<16, 2>("v_add_u32", sink); run3<8, 5>("ds_write_b64 + wait", sink); run3<8, 3>("ds_read_b64 + wait", sink);
     return 0;
 }
