@@ -944,3 +944,33 @@ def test_div_with_the_interleaved_b_build(torch_cuda, name, E):
         for k in got:
             ax = [i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
             _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})
+
+
+@pytest.mark.parametrize("E", [98304, 100000, 131072])
+def test_the_reference_regime_sizes_against_the_oracle(torch_cuda, E):
+    """The reference's own size regime (``long_dim_length`` defaults to 100 000: src/feinsum/measure.py:202; every fact of its
+    archives is taken there): three rounds of tiles on the 2048 waves -- exactly (98 304), with a ragged fourth round (100 000),
+    exactly four (131 072).  grad, div, face-mass x 4 as single launches and as the one fused launch of the wave operator (whose
+    bodies walk dynamically from three rounds on since round 5): sampled oracle slices at 1e-12, the fused launch bitwise the
+    three separate ones."""
+    torch = torch_cuda
+    exprs = [dg.div(), dg.grad(), dg.face_mass(4)]
+    devs = [_device_inputs(torch, e, E, 40 + k) for k, e in enumerate(exprs)]
+    devs[1]["J"], devs[1]["R"] = devs[0]["J"], devs[0]["R"]
+    stages = list(zip(exprs, devs))
+    slices = [slice(0, 48), slice(E // 2 - 7, E // 2 + 41), slice(E - 48, E)]
+    plain = f.evaluate_operator(stages, 0, fuse=False, wait=True)
+    for (expr, dev), outs in zip(stages, plain):
+        _sampled_oracle_check(expr, dev, outs, E, slices)
+    op = f.bind_operator(stages, 0)
+    assert op.entry_points == ("fe_waveop3d_f64",)
+    fused = f.evaluate_operator(stages, 0, wait=True)
+    info = _hip.last_launch_info()
+    assert info["bodies"] == 3 and bool(info["dynamic_walk"]) == (E != 0), info       # three rounds and more: tickets in the fused launch
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert torch.equal(a[k], b[k])
+    pair = f.evaluate_operator(stages[:2], 0, wait=True)                              # div + grad in one launch
+    for a, b in zip(pair, plain[:2]):
+        for k in a:
+            assert torch.equal(a[k], b[k])
