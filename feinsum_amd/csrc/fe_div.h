@@ -218,7 +218,30 @@ __device__ __forceinline__ void div3d_mfma_body(
 
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
-    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
+    const int64_t stride = (int64_t)nblk * G::WAVES;
+    // Quarter tiles (kIlv, static walk, one field; fe_common.h: kOpQuarterTail).  A static walk of R full rounds leaves r = nTiles mod
+    // (number of waves) tiles for a last, partial round: the SIMDs that get one have a whole tile more than the others -- 2.3 us of
+    // matrix work at E = 1e5, 8 % of the launch for 1.7 % of its elements (profiles/r05/tiles_div_100000_interleaved.txt).  When that
+    // round is at most an EIGHTH full its r tiles become 4 r quarter tiles of FOUR elements, one for each of the first 4 r waves
+    // (so every SIMD of the first r blocks gets one): a quarter tile runs on v_mfma_f64_4x4x4_4b alone -- its four blocks are four
+    // 4-row slices of the same 16-row A fragment the 16x16x4 instruction takes, the B operand is the four elements' values
+    // replicated over the blocks -- and costs 27 x 48 instead of 3888 matrix cycles.  Measured (profiles/r05/div_quarter_tail_ab.txt):
+    // E = 1e5 (r = 106) 25.3 -> 24.2 us, 1.02e5 (r = 231) -4.2 %; level at r = 356, +5 ... 9 % at r = 418 ... 452 (four quarter tiles
+    // cost a third more matrix cycles than the tile, and more than half of all SIMDs then carry one or two) -- hence the eighth.
+    // Bitwise the full-tile results (the same products in the same order; the 4x4x4 and 16x16x4 instructions round alike).
+    int64_t q_e0 = -1;            // first element of this wave's quarter tile, or -1
+    int64_t t_full = nTiles;      // tiles walked as full tiles
+    if constexpr (kIlv && !kDyn) {
+        if (op_flags & kOpQuarterTail) {
+            const int64_t r = nTiles % stride;
+            if (r > 0 && 8 * r <= stride) {
+                t_full = nTiles - r;
+                const int64_t w = (int64_t)bid * G::WAVES + wave;
+                if (w < 4 * r) q_e0 = t_full * G::TEL + 4 * w;
+            }
+        }
+    }
+    const int64_t tEnd = t_full;
     // nb fields share J and D ('xre,rij,xej->ei' x nb: tuning/impls/batched_xre_rij_xej_to_ei.py):
     // the wave walks (tile, field) units, field fastest; J is loaded with the first field of a
     // tile and stays in LDS until the last field's B fragments are built.
@@ -790,6 +813,30 @@ __device__ __forceinline__ void div3d_mfma_body(
     } else {
         if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
     }
+    // ---- the quarter tile of this wave (see above): loads, and the unit itself
+    bool q_issued = false;
+    auto issue_quarter_loads = [&]() {
+        q_issued = true;
+        const char* ub = reinterpret_cast<const char*>(field_in(P, 0)) + q_e0 * (NP * 8);
+        constexpr int QC = 4 * NP / 2;                     // 16-byte chunks of four rows (70)
+#pragma unroll
+        for (int x = 0; x < G::NPLANES; ++x) {
+            const char* up = ub + (int64_t)x * E * (NP * 8);
+#pragma unroll
+            for (int c = 0; c < (QC + 63) / 64; ++c)
+                if (c * 64 + lane < QC) {
+                    if (tload) glds16(up + (c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+                    else glds16_nt(up + (c * 64 + lane) * 16, lds_u + x * (G::PLANE_D * 8) + c * 1024);
+                }
+        }
+        // J: nine rows of four doubles, compact: j[k * 4 + element]
+        if (lane < 18) glds16(reinterpret_cast<const char*>(J) + ((int64_t)(lane >> 1) * E + q_e0) * 8 + (lane & 1) * 16, lds_j);
+    };
+    constexpr int kQuarterLoads = G::NPLANES * ((4 * NP / 2 + 63) / 64) + 1, kQuarterStores = (4 * NP / 2 + 63) / 64;
+    (void)kQuarterLoads;
+    if constexpr (kIlv && !kDyn) {
+        if (q_e0 >= 0 && !(tile < tEnd)) issue_quarter_loads();   // a wave without a full tile: its quarter tile comes first
+    }
     const bool younger_half = bid >= (nblk + 1) / 2;
     int iteration = 0, fk = 0;
     int dbg_it = 0;   // (experiments build: units done by this wave, for the per-tile stamps of kDbg & 128)
@@ -923,6 +970,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     resolve_next_tile(tile, fk, next_new_tile, nt);
                     if (nt < tEnd) issue_loads(nt, nk, next_new_tile);
+                    else if (!kDyn && q_e0 >= 0) issue_quarter_loads();   // behind this wave's last full tile: its quarter tile
                     FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the last B fragments built, the next unit's loads issued
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1152,6 +1200,79 @@ __device__ __forceinline__ void div3d_mfma_body(
         ++dbg_it;
         fk = nk;
         tile = nt;
+    }
+    if constexpr (kIlv && !kDyn) {
+        if (q_e0 >= 0) {
+            // ---- the quarter tile: elements q_e0 .. q_e0 + 3.  Lane (g, n) works for element n & 3 (the four blocks n >> 2 of the
+            //      4x4x4_4b instruction see the same four elements); block b of an MFMA with the 16-row fragment a_big(t, ., .) is
+            //      rows 16 t + 4 b .. + 3, so the lane receives out[16 t + 4 (n >> 2) + g][element n & 3].
+            if (first) wait_vmcnt<0>();                      // (no full tile before it)
+            else wait_vmcnt<G::STORES>();                    // younger than its loads: the last full tile's stores
+            const int el = n & 3;
+            double jac[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) jac[k] = L->j[k * 4 + el];
+            auto read_quad = [&](int jq, double (&ux)[3]) {
+                const int j = 4 * jq + g;
+                const int jc = j < NP ? j : 0;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) ux[x] = j < NP ? L->u[x][el * NP + jc] : 0.0;
+            };
+            auto build_quad = [&](const double (&ux)[3], double (&bq)[3]) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double v = jac[r] * ux[0];
+#pragma unroll
+                    for (int x = 1; x < 3; ++x) v = __builtin_fma(jac[x * 3 + r], ux[x], v);
+                    bq[r] = v;
+                }
+            };
+            double acc4[G::BT > 0 ? G::BT : 1], accs[G::NS > 0 ? G::NS : 1];
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t) acc4[t] = 0.0;
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
+            double ux[2][3], bq[2][3];
+            read_quad(0, ux[0]);
+            read_quad(1, ux[1]);
+            build_quad(ux[0], bq[0]);
+#pragma unroll
+            for (int jq = 0; jq < G::KSJ; ++jq) {
+                const int cur = jq & 1, nxt = cur ^ 1;
+                if (jq + 2 < G::KSJ) read_quad(jq + 2, ux[cur]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int t = 0; t < G::BT; ++t) acc4[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_big(t, jq, r), bq[cur][r], acc4[t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < G::NS; ++q)
+                        accs[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(as_lane[((jq * 3 + r) * G::NS + q) * 16], bq[cur][r], accs[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (jq + 1 < G::KSJ) build_quad(ux[nxt], bq[nxt]);
+            }
+            double* ob = L->o;                               // [4][NP], compact
+#pragma unroll
+            for (int t = 0; t < G::BT; ++t) ob[el * NP + 16 * t + 4 * (n >> 2) + g] = acc4[t];
+#pragma unroll
+            for (int q = 0; q < G::NS; ++q) {
+                const int i = 16 * G::BT + 4 * q + g;
+                if ((n >> 2) == 0 && i < NP) ob[el * NP + i] = accs[q];
+            }
+            wave_lds_fence();
+            double* op = field_out(P, 0) + q_e0 * NP;
+            constexpr int QC = 4 * NP / 2;
+#pragma unroll
+            for (int c = 0; c < kQuarterStores; ++c) {
+                const int qc = c * 64 + lane;
+                if (qc < QC) {
+                    const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * qc);
+                    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
+                }
+            }
+            wave_lds_fence();
+        }
     }
 #ifdef FE_EXPERIMENTS
     if (kDbg & 128) {   // stamps out: the tile stamps, and {kernel entry, -, loop end, XCC_ID | HW_ID << 8 | tiles << 40} as fe_grad.h

@@ -381,6 +381,10 @@ int write_through_flag(int64_t output_bytes) {
 constexpr long long kDivInterleaveTiles = 37500;
 std::atomic<long long> g_div_interleave_tiles{[] { const char* e = getenv("FEINSUM_DIV_INTERLEAVE_TILES"); return e ? atoll(e) : kDivInterleaveTiles; }()};
 
+// ... and the tiles behind the last full round of such a launch as quarter tiles (fe_div.h, kOpQuarterTail): $FEINSUM_DIV_QUARTER_TAIL /
+// fe_set_div_quarter_tail
+std::atomic<int> g_div_quarter_tail{[] { const char* e = getenv("FEINSUM_DIV_QUARTER_TAIL"); return e ? atoi(e) : 1; }()};
+
 // the same flag for the eight-wave p = 5 kernels (compute bound at every size): $FEINSUM_PHASE_PRIORITY_P5 / fe_set_phase_priority_p5
 std::atomic<int> g_phase_priority_p5{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_P5"); return e ? atoi(e) : 0; }()};
 int phase_priority_flag_p5() { return g_phase_priority_p5.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0; }
@@ -806,8 +810,10 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
                     tail_static_tiles(nTiles, g.x, G::WAVES) == nTiles) {   // a short launch (static walk): the interleaved form
                     static PerDeviceOnce once_ilv;
                     if (int rc = configured(once_ilv, fe::div3d_mfma_ilv_kernel<NP>, "div Np=35, B build interleaved", G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
-                    hipLaunchKernelGGL((fe::div3d_mfma_ilv_kernel<NP>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT);
-                    note_launch(false, opT & ~fe::kOpStoresWriteThrough, g.x, G::WAVES, nTiles, nTiles, 4);
+                    const int64_t waves = (int64_t)g.x * G::WAVES, ragged = nTiles % waves;   // (the kernel's own rule: fe_div.h)
+                    const int qflag = (nb == 1 && ragged > 0 && 8 * ragged <= waves && g_div_quarter_tail.load(std::memory_order_relaxed)) ? fe::kOpQuarterTail : 0;
+                    hipLaunchKernelGGL((fe::div3d_mfma_ilv_kernel<NP>), g, b, G::LDS_BYTES, s, J, D, P, nb, E, nTiles, opT | qflag);
+                    note_launch(false, opT & ~fe::kOpStoresWriteThrough, g.x, G::WAVES, nTiles, nTiles, 4 | (qflag ? 8 : 0));
                     break;
                 }
             }
@@ -2181,6 +2187,10 @@ int fe_last_launch_info(int64_t* out, int32_t n) {
                                             L.tiles, L.static_tiles};
     for (int k = 0; k < n && k < FE_LAST_LAUNCH_INFO; ++k) out[k] = v[k];
     return n < FE_LAST_LAUNCH_INFO ? n : FE_LAST_LAUNCH_INFO;
+}
+
+int fe_set_div_quarter_tail(int32_t on) {
+    return g_div_quarter_tail.exchange(on ? 1 : 0);
 }
 
 int fe_set_tail_min_rounds(int32_t rounds) {

@@ -448,7 +448,7 @@ int fe_set_write_through_mib(int32_t mib);
 /* What the launcher decided for the MFMA launch this THREAD enqueued last (p = 1..4 grad / div / face-mass and the fused
  * launches; other paths leave it unchanged): out[0..n) = {valid, dynamic walk (tickets behind the static rounds), plain
  * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 2: div with the
- * interleaved B build), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
+ * interleaved B build; bit 3: with a quarter-tile tail), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
  * written.  For reports (bench.py prints these instead of re-deriving the launcher's rules). */
 #define FE_LAST_LAUNCH_INFO 10
 int fe_last_launch_info(int64_t* out, int32_t n);
@@ -457,6 +457,10 @@ int fe_last_launch_info(int64_t* out, int32_t n);
  * k-quad by k-quad between the MFMA groups of the same wave (default 37500 = E 6e5: -3 ... -6 % at E = 8e4 ... 3e5, level above;
  * 0 = never; also FEINSUM_DIV_INTERLEAVE_TILES).  Returns the previous setting.  Bitwise the results of the plain kernel. */
 int64_t fe_set_div_interleave(int64_t tiles);
+/* ... and, under the static walk with one field, the tiles behind the last full round -- when they fill at most an eighth of a
+ * round -- as quarter tiles of four elements, one per wave (default on: E = 1e5 -4 %; also FEINSUM_DIV_QUARTER_TAIL).  Returns
+ * the previous setting.  Bitwise the results of the plain kernel. */
+int fe_set_div_quarter_tail(int32_t on);
 /* Phase priorities in the eight-wave kernels of tetrahedra p = 5 (grad, div): the waves' f64 VALU phases at raised issue
  * priority, their matrix phases at priority 0 (default off: -1 % for div at E >= 1e6, +-1 % for grad; also
  * FEINSUM_PHASE_PRIORITY_P5).  Returns the previous setting.  Results do not depend on it. */

@@ -928,6 +928,9 @@ def test_div_with_the_interleaved_b_build(torch_cuda, name, E):
     assert before == 37500                                    # the default: launches of up to 6e5 elements
     if name != "batched_div3" or E <= 131072:                 # (batched launches take it under the static walk only)
         assert info["interleaved"] and not info_plain["interleaved"], (info, info_plain)
+    # E = 100 000: 6250 tiles = three rounds of 2048 waves + 106 -- at most an eighth of a round: those run as 424 quarter tiles of
+    # four elements on v_mfma_f64_4x4x4_4b (fe_div.h, kOpQuarterTail); one field only
+    assert info.get("quarter_tail") == (E == 100000 and name != "batched_div3"), info
     for k in got:
         assert np.array_equal(got[k], plain[k]), (name, E, k)
     if E <= 10007:
