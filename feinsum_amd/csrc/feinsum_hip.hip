@@ -2341,13 +2341,37 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
     // every row of J and every output plane starts on a 16-byte boundary) and at least one full tile; else the tiled kernel
     // div and face-mass likewise (fe_div_f32.h, fe_facemass_f32.h)
     const bool grad_lower = family == FE_FAMILY_GRAD && ndim == 3 && (a->Np == 20 || a->Np == 10 || a->Np == 4);   // p = 1 ... 3 (round 4)
-    const bool mfma_shape = grad_lower || (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35) || (family == FE_FAMILY_DIV && ndim == 3 && a->Np == 35) ||
-                            (family == FE_FAMILY_FACEMASS && a->Np == 35 && nf == 4 && Nfp == 15);
+    const bool div_lower = family == FE_FAMILY_DIV && ndim == 3 && (a->Np == 20 || a->Np == 10 || a->Np == 4);        // p = 1 ... 3 (round 5)
+    const bool fm_lower = family == FE_FAMILY_FACEMASS && nf == 4 &&
+                          ((a->Np == 20 && Nfp == 10) || (a->Np == 10 && Nfp == 6) || (a->Np == 4 && Nfp == 3));          // p = 1 ... 3 (round 5)
+    const bool mfma_shape = grad_lower || div_lower || (family == FE_FAMILY_GRAD && ndim == 3 && a->Np == 35) || (family == FE_FAMILY_DIV && ndim == 3 && a->Np == 35) ||
+                            (family == FE_FAMILY_FACEMASS && a->Np == 35 && nf == 4 && Nfp == 15) || fm_lower;
     if (mfma_shape && a->variant != FE_VARIANT_TILED && a->E % 4 == 0 && a->E >= 16) {
         bool aligned = ((reinterpret_cast<uintptr_t>(a->J) | reinterpret_cast<uintptr_t>(a->D)) & 15u) == 0;
         for (int k = 0; k < b; ++k)
             aligned = aligned && vin[k] && vout[k] && ((reinterpret_cast<uintptr_t>(vin[k]) | reinterpret_cast<uintptr_t>(vout[k])) & 15u) == 0;
-        if (aligned && family == FE_FAMILY_DIV) {
+        if (aligned && div_lower) {   // fe_div_f32.h: the kernel over the geometry (Np, M)
+            auto go_np = [&](auto geom, auto kernel, const char* what, PerDeviceOnce& once) -> int {
+                using G = decltype(geom);
+                const int64_t nTiles = a->E / G::TEL;
+                if (nTiles == 0) return 1;   // too few elements for a wave tile: the tiled kernel
+                if (int rc = configured(once, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+                const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+                if (blocks > cap) blocks = cap;
+                for (int k = 0; k < b; ++k)
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s, reinterpret_cast<const float*>(a->J),
+                                       reinterpret_cast<const float*>(a->D), reinterpret_cast<const float*>(vin[k]),
+                                       reinterpret_cast<float*>(vout[k]), a->E, nTiles, opT);
+                FE_HIP_CHECK(hipGetLastError());
+                return FE_OK;
+            };
+            static PerDeviceOnce once20, once10, once4;
+            const int rc = a->Np == 20 ? go_np(fe::DivF32GeomT<20, 1>{}, fe::div3d_mfma_f32_np_kernel<20, 1>, "div float32 Np=20 M=1", once20)
+                           : a->Np == 10 ? go_np(fe::DivF32GeomT<10, 3>{}, fe::div3d_mfma_f32_np_kernel<10, 3>, "div float32 Np=10 M=3", once10)
+                                         : go_np(fe::DivF32GeomT<4, 5>{}, fe::div3d_mfma_f32_np_kernel<4, 5>, "div float32 Np=4 M=5", once4);
+            if (rc <= 0) return rc;
+        } else if (aligned && family == FE_FAMILY_DIV) {
             // the measured alternatives (profiles/r03/float32_div_facemass.txt) stay selectable in the experiment build
 #ifdef FE_EXPERIMENTS
             static const int ring = [] { const char* e = getenv("FEINSUM_F32_DIV_RING"); return e && atoi(e) == 1 ? 1 : 2; }();
@@ -2386,7 +2410,34 @@ int fe_launch_f32(int32_t family, const fe_argpack* a, void* stream) {
 #endif
             return go(fe::DivF32Geom<2>{}, fe::div3d_mfma_f32_kernel<2, true>, "div float32 Np=35", once2);
         }
-        if (aligned && family == FE_FAMILY_FACEMASS) {
+        if (aligned && fm_lower) {   // fe_facemass_f32.h: the kernel over the geometry (Np, Nfp, M)
+            auto go_np = [&](auto geom, auto kernel, const char* what, PerDeviceOnce& once) -> int {
+                using G = decltype(geom);
+                const int64_t nTiles = a->E / G::TEL;
+                if (nTiles == 0) return 1;   // too few elements for a wave tile: the tiled kernel
+                if (int rc = configured(once, kernel, what, G::LDS_BYTES, 256, G::BLOCKS_PER_CU)) return rc;
+                int64_t blocks = (nTiles + G::WAVES - 1) / G::WAVES;
+                const int64_t cap = (int64_t)G::BLOCKS_PER_CU * device_cu_count();
+                if (blocks > cap) blocks = cap;
+                for (int k0 = 0; k0 < b; k0 += fe::kMaxFields) {   // groups of up to kMaxFields fields share J and the fragments
+                    const int nb = b - k0 < fe::kMaxFields ? b - k0 : fe::kMaxFields;
+                    fe::FieldPtrs P;
+                    for (int k = 0; k < fe::kMaxFields; ++k) {
+                        P.v[k] = vin[k0 + (k < nb ? k : 0)];
+                        P.out[k] = vout[k0 + (k < nb ? k : 0)];
+                    }
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), G::LDS_BYTES, s, reinterpret_cast<const float*>(a->J),
+                                       reinterpret_cast<const float*>(a->D), P, nb, a->E, nTiles, jl, rl);
+                }
+                FE_HIP_CHECK(hipGetLastError());
+                return FE_OK;
+            };
+            static PerDeviceOnce once20, once10, once4;
+            const int rc = a->Np == 20 ? go_np(fe::FmF32GeomT<20, 10, 1>{}, fe::facemass_mfma_f32_np_kernel<20, 10, 1>, "face-mass float32 Np=20 M=1", once20)
+                           : a->Np == 10 ? go_np(fe::FmF32GeomT<10, 6, 2>{}, fe::facemass_mfma_f32_np_kernel<10, 6, 2>, "face-mass float32 Np=10 M=2", once10)
+                                         : go_np(fe::FmF32GeomT<4, 3, 4>{}, fe::facemass_mfma_f32_np_kernel<4, 3, 4>, "face-mass float32 Np=4 M=4", once4);
+            if (rc <= 0) return rc;
+        } else if (aligned && family == FE_FAMILY_FACEMASS) {
             using G = fe::FmF32Geom;
             static PerDeviceOnce once;
             auto kernel = fe::facemass_mfma_f32_kernel<true>;

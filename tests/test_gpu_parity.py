@@ -725,6 +725,10 @@ F32_CASES = {
     "grad_p3": lambda: dg.grad(20), "div_p2": lambda: dg.div(10), "grad_p5": lambda: dg.grad(56),
     # round 4: the float32 MFMA grad kernel is templated on Np (p = 1 ... 3 ran on the tiled kernel before)
     "grad_p1": lambda: dg.grad(4), "grad_p2": lambda: dg.grad(10), "grad_t_p3": lambda: dg.grad_t(20), "batched_grad_b3_p2": lambda: dg.batched_grad(3, 10),
+    # round 5: the float32 MFMA div kernel over the geometry (Np, M): p = 1 ... 3
+    "face_mass_p1": lambda: dg.face_mass(4, Np=4, Nfp=3), "face_mass_p2_b3": lambda: dg.face_mass(3, Np=10, Nfp=6), "face_mass_p3": lambda: dg.face_mass(4, Np=20, Nfp=10),
+    "face_mass_p3_ifj_fe": lambda: dg.face_mass_ifj_fe(2, Np=20, Nfp=10), "face_mass_p2_b9": lambda: dg.face_mass(9, Np=10, Nfp=6),
+    "div_p1": lambda: dg.div(4), "div_p3": lambda: dg.div(20), "div_t_p2": lambda: dg.div_t(10), "batched_div_b2_p3": lambda: dg.batched_div(2, 20),
     "face_mass_p5": lambda: dg.face_mass(4, Np=56, Nfp=21), "face_mass_b9": lambda: dg.face_mass(9),
     "div_t": lambda: dg.div_t(), "face_mass_b1": lambda: dg.face_mass(1), "face_mass_b2": lambda: dg.face_mass(2),
     "face_mass_b3": lambda: dg.face_mass(3), "face_mass_jfi_fe": lambda: dg.face_mass_jfi_fe(4), "face_mass_fji": lambda: dg.face_mass_fji(2),
