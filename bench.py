@@ -250,33 +250,23 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def _build_flags():
+def _build_info() -> dict:
+    """feinsum_amd/libfeinsum_hip.build.json, written by __graft_entry__.build_library when it compiles the library: the flags
+    and the compiler it was built with.  Read from the file -- never asked of the compiler here: bench.py has initialised the
+    GPU by the time it needs the hash (under rocprofv3 --pmc the profiler has, before the program starts), and such a process
+    must not start another program."""
     try:
-        import __graft_entry__ as entry
-
-        return list(entry.HIPCC_FLAGS)
-    except Exception:      # noqa: BLE001
-        return ["unknown"]
+        return json.loads((ROOT / "feinsum_amd" / "libfeinsum_hip.build.json").read_text())
+    except (OSError, ValueError):
+        return {}
 
 
-_COMPILER_VERSION = None
+def _build_flags():
+    return list(_build_info().get("hipcc_flags") or ["unknown"])
 
 
 def _compiler_version() -> str:
-    """First lines of ``hipcc --version`` (HIP version and the clang it drives), or "unknown"; asked once."""
-    global _COMPILER_VERSION
-    if _COMPILER_VERSION is None:
-        import shutil
-        import subprocess
-
-        exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        try:
-            out = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout
-            keep = [ln.strip() for ln in out.splitlines() if ln.startswith(("HIP version", "AMD clang version", "clang version"))]
-            _COMPILER_VERSION = " | ".join(keep) or "unknown"
-        except Exception:  # noqa: BLE001
-            _COMPILER_VERSION = "unknown"
-    return _COMPILER_VERSION
+    return str(_build_info().get("compiler") or "unknown")
 
 
 def committed_counters(workload: str, E: int):
