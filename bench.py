@@ -134,12 +134,12 @@ def gather_rank_reports(report: dict, device=None) -> list:
 
     mode = report.get("placement_mode", "separate")
     row = [report["elements"], report["kernel_ms"], report["wall_ms"], _PLACEMENT_MODES.index(mode) if mode in _PLACEMENT_MODES else 1,
-           report.get("unsplit_arrays", 0), report.get("allocator_ms", 0.0), report.get("search_ms", 0.0)]
+           report.get("unsplit_arrays", 0), report.get("allocator_ms", 0.0), report.get("search_ms", 0.0), report.get("release_ms", 0.0)]
     out = []
     for rank, r in enumerate(parallel.gather_rows(row, device)):
         out.append({"rank": rank, "elements": int(r[0]), "kernel_ms": round(r[1], 5), "wall_ms": round(r[2], 5),
                     "placement_mode": _PLACEMENT_MODES[int(r[3])], "unsplit_arrays": int(r[4]), "allocator_ms": round(r[5], 1),
-                    "allocator_search_ms": round(r[6], 1)})
+                    "allocator_search_ms": round(r[6], 1), "allocator_release_ms": round(r[7], 1)})
     return out
 
 
@@ -724,7 +724,7 @@ def main() -> None:
                                     "placement_mode": ("split" if placement_report.get("mode") == "split" else
                                                        "separate (split allocator failed)" if "fallback" in placement_report else "separate"),
                                     "unsplit_arrays": pool_r.get("unsplit_arrays", 0) or 0, "allocator_ms": placement_report.get("allocator_ms", 0.0),
-                                    "search_ms": pool_r.get("search_ms", 0.0) or 0.0}, device)
+                                    "search_ms": pool_r.get("search_ms", 0.0) or 0.0, "release_ms": pool_r.get("release_ms", 0.0) or 0.0}, device)
 
     # the reference's own protocol on the same bound launch (every rank, no barrier inside)
     protocol_ms = None
