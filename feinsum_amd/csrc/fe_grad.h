@@ -253,8 +253,30 @@ __device__ __forceinline__ void grad3d_mfma_body(
     const int n = lane & 15, g = lane >> 4;
     constexpr bool kNT = (kDbg & 16) == 0;
 
-    const int64_t stride = (int64_t)nblk * G::WAVES, tEnd = nTiles;
+    const int64_t stride = (int64_t)nblk * G::WAVES;
     int64_t tile = (int64_t)bid * G::WAVES + wave;
+    // Quarter tiles (plain launches of one field on the static walk, one sub-tile per wave tile; fe_common.h: kOpQuarterTail --
+    // the reason is that of fe_div.h).  R >= 1 full rounds leave r = nTiles mod (number of waves) tiles; when the launcher asks
+    // for it (feinsum_hip.hip: grad_quarter_flag) the r tiles become 4 r quarter tiles of FOUR elements, one for each of the first
+    // 4 r waves, behind the wave's last full tile.  Stage 1 of a quarter tile runs on v_mfma_f64_4x4x4_4b with the SAME A fragments (its four
+    // blocks are the four 4-row slices of a 16-row fragment; B = the four elements' values, replicated over the blocks): lane (g, n)
+    // receives row g + 4 (n >> 2) of every 16-row tile for element n & 3, i.e. slot 4 t + (n >> 2) of lane group g.  The three r of
+    // an i are then on different lanes, so stage 2 goes through LDS: tmp[element][g][slot], and every lane combines whole (element, i)
+    // entries -- consecutive lanes = consecutive doubles of out[x, q_e0 : q_e0 + 4, :], stored straight from registers.
+    // Same products in the same order as a full tile: bitwise the same results.
+    int64_t q_e0 = -1;            // first element of this wave's quarter tile, or -1
+    int64_t t_full = nTiles;      // tiles walked as full tiles
+    if constexpr (kPlain && !kPrep && M == 1) {
+        if ((op_flags & kOpQuarterTail) && nb == 1 && !(kDyn && tail != nullptr)) {
+            const int64_t r = nTiles % stride;
+            if (r > 0 && 4 * r <= stride && nTiles > stride) {   // (what is possible; the launcher sets the flag by its own, narrower rule)
+                t_full = nTiles - r;
+                const int64_t w = (int64_t)bid * G::WAVES + wave;
+                if (w < 4 * r) q_e0 = t_full * G::TEL + 4 * w;
+            }
+        }
+    }
+    const int64_t tEnd = t_full;
 
     double afrag[G::RT][G::KS];
     // experiment (kDbg & 128): the walk covers both halves of the element range at once (see fe_div.h, kDbg & 4)
@@ -545,6 +567,20 @@ __device__ __forceinline__ void grad3d_mfma_body(
         }
     }
 
+    // ---- the quarter tile of this wave (see the top): its loads -- four rows of u (contiguous), nine times four doubles of J, compact
+    //      as j[k * 4 + element] -- and, behind the loop, the unit itself
+    constexpr int kQuarterChunks = 4 * NP / 2;                             // 16-byte chunks of four rows of u
+    constexpr int kQuarterLoads = (kQuarterChunks + 63) / 64 + 1;
+    auto issue_quarter_loads = [&](unsigned lds_u, unsigned lds_j) {
+        const char* ub_ = reinterpret_cast<const char*>(P.u[0]) + q_e0 * (NP * 8);
+#pragma unroll
+        for (int c = 0; c < (kQuarterChunks + 63) / 64; ++c)
+            if (c * 64 + lane < kQuarterChunks) {
+                if (tload) glds16(ub_ + (c * 64 + lane) * 16, lds_u + c * 1024);
+                else glds16_nt(ub_ + (c * 64 + lane) * 16, lds_u + c * 1024);
+            }
+        if (lane < 18) glds16(reinterpret_cast<const char*>(P.j[0]) + ((int64_t)(lane >> 1) * E + q_e0) * 8 + (lane & 1) * 16, lds_j);
+    };
     int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
     const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
@@ -604,6 +640,10 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
                 else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
             }
+        } else if (q_e0 >= 0) {   // (static walk, one field) the last full tile: behind its loads go the quarter tile's
+            issue_quarter_loads(lds_addr_uniform(L->u[ub ^ 1]), lds_addr_uniform(L->j[jbuf ^ 1]));
+            if (first) wait_vmcnt<kQuarterLoads>();
+            else wait_vmcnt<kQuarterLoads + G::STORES>();
         } else {
             if (kDyn && extra) wait_vmcnt<G::STORES + 1>();
             else if (first || (kDbg & 2)) wait_vmcnt<0>();
@@ -617,6 +657,51 @@ __device__ __forceinline__ void grad3d_mfma_body(
         tile = nt;
         ub ^= 1;
         if (next_new_tile) jbuf ^= 1;
+    }
+    if constexpr (kPlain && !kPrep && M == 1) {
+        if (q_e0 >= 0) {
+            wait_vmcnt<G::STORES>();                         // younger than the quarter tile's loads: the last full tile's stores
+            const double* ut = L->u[ub];
+            const double* jt = L->j[jbuf];
+            const int el = n & 3;
+            double bq[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const int j = 4 * ks + g;
+                const double b = ut[el * NP + (j < NP ? j : 0)];
+                bq[ks] = (j < NP) ? b : 0.0;
+            }
+            double acc1[G::RT];
+#pragma unroll
+            for (int t = 0; t < G::RT; ++t) acc1[t] = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) acc1[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(afrag[t][ks], bq[ks], acc1[t], 0, 0, 0);
+            double* tb = LO->o[0];                           // tmp[element][g][slot]: 16 x 4 RT doubles (448 of the buffer's 560)
+            static_assert(16 * 4 * G::RT <= G::SUB_D, "the quarter tile's tmp fits one transposition buffer");
+#pragma unroll
+            for (int t = 0; t < G::RT; ++t) tb[(el * 4 + g) * (4 * G::RT) + 4 * t + (n >> 2)] = acc1[t];
+            wave_lds_fence();
+            double* const o0 = grad_plane_out(P, 0, 0) + q_e0 * NP;
+#pragma unroll
+            for (int c = 0; c < (4 * NP + 63) / 64; ++c) {
+                const int p = c * 64 + lane;                 // entry (element p / NP, i = p % NP) of all three planes
+                if (p < 4 * NP) {
+                    const int e2 = p / NP, i = p - e2 * NP;
+                    const int gi = i / G::TG, k = i - gi * G::TG;
+                    const double* tp = tb + (e2 * 4 + gi) * (4 * G::RT) + 3 * k;
+                    const double t0 = tp[0], t1 = tp[1], t2 = tp[2];
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        const double j0 = jt[(x * 3 + 0) * 4 + e2], j1 = jt[(x * 3 + 1) * 4 + e2], j2 = jt[(x * 3 + 2) * 4 + e2];
+                        const double v = __builtin_fma(j2, t2, __builtin_fma(j1, t1, j0 * t0));
+                        __builtin_nontemporal_store(v, o0 + (int64_t)x * E * NP + p);
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
     }
     if constexpr (kDyn) {
         if (reportedb) {   // the last wave of a pool to report leaves the pool's counters zeroed (younger than the report: this unit's stores)

@@ -385,6 +385,17 @@ std::atomic<long long> g_div_interleave_tiles{[] { const char* e = getenv("FEINS
 // fe_set_div_quarter_tail
 std::atomic<int> g_div_quarter_tail{[] { const char* e = getenv("FEINSUM_DIV_QUARTER_TAIL"); return e ? atoi(e) : 1; }()};
 
+// ... and of short grad launches (fe_grad.h; one field, static walk, one sub-tile per wave tile): $FEINSUM_GRAD_QUARTER_TAIL /
+// fe_set_grad_quarter_tail.  The rule is the kernel's own (at least one full round, the ragged one at most an eighth full).
+constexpr int kGradQuarterDen = 8;
+std::atomic<int> g_grad_quarter_tail{[] { const char* e = getenv("FEINSUM_GRAD_QUARTER_TAIL"); return e ? atoi(e) : 1; }()};
+int grad_quarter_flag(int m, int nb, int64_t nTiles, int64_t waves) {
+    const int64_t ragged = nTiles % waves;
+    const int setting = g_grad_quarter_tail.load(std::memory_order_relaxed);   // 0 off, 1 the default rule, n >= 4: ragged <= waves / n
+    const int64_t den = setting >= 4 ? setting : kGradQuarterDen;
+    return (m == 1 && nb == 1 && setting != 0 && nTiles > waves && ragged > 0 && den * ragged <= waves) ? fe::kOpQuarterTail : 0;
+}
+
 // the same flag for the eight-wave p = 5 kernels (compute bound at every size): $FEINSUM_PHASE_PRIORITY_P5 / fe_set_phase_priority_p5
 std::atomic<int> g_phase_priority_p5{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_P5"); return e ? atoi(e) : 0; }()};
 int phase_priority_flag_p5() { return g_phase_priority_p5.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0; }
@@ -692,7 +703,7 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                     break;
                 }
             }
-            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (as the product's static walk)
+            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8) | grad_quarter_flag(M, nb, nTiles, (int64_t)g.x * G::WAVES);   // (as the product's static walk)
             hipLaunchKernelGGL((fe::grad3d_mfma_kernel<NP, M, 32>), g, b, G::LDS_BYTES + fe::kDbgTileLdsBytes, s, P, D, nullptr, nb, nx, E, nTiles, opT);
             break;
         case 64: FE_GRAD_CASE(64); break;
@@ -731,9 +742,9 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                     }
                 }
             }
-            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8);   // (static walk, one field: a short launch)
+            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8) | grad_quarter_flag(M, nb, nTiles, (int64_t)g.x * G::WAVES);   // (static walk, one field: a short launch)
             FE_GRAD_CASE(0);
-            note_launch(false, opT, g.x, G::WAVES, nTiles, nTiles);
+            note_launch(false, opT, g.x, G::WAVES, nTiles, nTiles, (opT & fe::kOpQuarterTail) ? 8 : 0);
             break;
     }
 #undef FE_GRAD_CASE
@@ -2191,6 +2202,10 @@ int fe_last_launch_info(int64_t* out, int32_t n) {
 
 int fe_set_div_quarter_tail(int32_t on) {
     return g_div_quarter_tail.exchange(on ? 1 : 0);
+}
+
+int fe_set_grad_quarter_tail(int32_t on) {
+    return g_grad_quarter_tail.exchange(on < 0 ? 0 : (on == 2 || on == 3) ? 1 : on);
 }
 
 int fe_set_tail_min_rounds(int32_t rounds) {

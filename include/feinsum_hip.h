@@ -448,7 +448,7 @@ int fe_set_write_through_mib(int32_t mib);
 /* What the launcher decided for the MFMA launch this THREAD enqueued last (p = 1..4 grad / div / face-mass and the fused
  * launches; other paths leave it unchanged): out[0..n) = {valid, dynamic walk (tickets behind the static rounds), plain
  * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 2: div with the
- * interleaved B build; bit 3: with a quarter-tile tail), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
+ * interleaved B build; bit 3: div or grad with a quarter-tile tail), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
  * written.  For reports (bench.py prints these instead of re-deriving the launcher's rules). */
 #define FE_LAST_LAUNCH_INFO 10
 int fe_last_launch_info(int64_t* out, int32_t n);
@@ -461,6 +461,10 @@ int64_t fe_set_div_interleave(int64_t tiles);
  * round -- as quarter tiles of four elements, one per wave (default on: E = 1e5 -4 %; also FEINSUM_DIV_QUARTER_TAIL).  Returns
  * the previous setting.  Bitwise the results of the plain kernel. */
 int fe_set_div_quarter_tail(int32_t on);
+/* The same for grad launches of one field on the static walk (tetrahedra p = 4): the four elements of a quarter tile run stage 1
+ * on v_mfma_f64_4x4x4_4b with the fragments of the full tiles and stage 2 through LDS (default on; also
+ * FEINSUM_GRAD_QUARTER_TAIL).  Returns the previous setting.  Bitwise the results of the full tiles. */
+int fe_set_grad_quarter_tail(int32_t on);
 /* Phase priorities in the eight-wave kernels of tetrahedra p = 5 (grad, div): the waves' f64 VALU phases at raised issue
  * priority, their matrix phases at priority 0 (default off: -1 % for div at E >= 1e6, +-1 % for grad; also
  * FEINSUM_PHASE_PRIORITY_P5).  Returns the previous setting.  Results do not depend on it. */

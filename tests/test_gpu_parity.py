@@ -953,6 +953,46 @@ def test_div_with_the_interleaved_b_build(torch_cuda, name, E):
             _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})
 
 
+@pytest.mark.parametrize("name", ["grad", "grad_t"])
+@pytest.mark.parametrize("E", [100000, 100007, 33000, 68736, 36864 + 64])
+def test_grad_with_a_quarter_tile_tail(torch_cuda, name, E):
+    """Round 5: a short grad launch (one field, static walk) whose last round is at most an eighth full runs that round's tiles as
+    quarter tiles of four elements (fe_grad.h, kOpQuarterTail; fe_set_grad_quarter_tail): stage 1 on v_mfma_f64_4x4x4_4b with the
+    fragments of the full tiles, stage 2 through LDS.  BITWISE the full-tile launch (the same products in the same order), and
+    against the oracle on the elements of the quarter tiles.  E = 100 000: three rounds + 106 tiles; 100 007: the same with seven
+    elements behind the last tile; 33 000: ONE full round + 14 tiles (a wave's quarter tile follows its first tile); 68 736: two
+    rounds + 200; 36 928: one round + 260 tiles -- more than an eighth, no quarter tiles."""
+    torch = torch_cuda
+    expr = {"grad": dg.grad, "grad_t": dg.grad_t}[name]()
+    host = generate_host_input_arrays(expr, E, np_seed=E + 11)
+    before = _hip.set_grad_quarter_tail(True)
+    try:
+        got = _run(torch, expr, host)
+        info = _hip.last_launch_info()
+        _hip.set_grad_quarter_tail(False)
+        full = _run(torch, expr, host)
+        info_full = _hip.last_launch_info()
+    finally:
+        _hip.set_grad_quarter_tail(before)
+    assert before is True                                      # the default
+    assert not info["dynamic_walk"] and not info_full.get("quarter_tail"), (info, info_full)
+    assert bool(info.get("quarter_tail")) == (E != 36864 + 64), info
+    for k in got:
+        assert np.array_equal(got[k], full[k]), (name, E, k)
+    tiles = E // 16
+    first = (tiles - tiles % 2048) * 16                        # the first element behind the full rounds
+    idx = np.unique(np.concatenate([np.arange(0, 32), np.arange(first - 16, min(E, first + 96)), np.arange(E - 40, E)]))
+    sub = {}
+    for a in sorted(expr.all_args):
+        shape = expr.arg_to_shape[a]
+        ax = [i for i, d in enumerate(shape) if isinstance(d, f.SizeParam)]
+        sub[a] = np.take(host[a], idx, axis=ax[0]) if ax else host[a]
+    ref = _oracle(expr, sub)
+    ax = [i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
+    for k in got:
+        _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})
+
+
 @pytest.mark.parametrize("E", [98304, 100000, 131072])
 def test_the_reference_regime_sizes_against_the_oracle(torch_cuda, E):
     """The reference's own size regime (``long_dim_length`` defaults to 100 000: src/feinsum/measure.py:202; every fact of its
