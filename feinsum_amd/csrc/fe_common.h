@@ -117,8 +117,17 @@ constexpr int kOpQuarterTail = 128;
 // One 16-byte write-through store per lane, in the addressing form the compiler gives its own stores (wave-uniform base in
 // SGPRs + one 32-bit lane offset + immediate): with a 64-bit VGPR address per store the same instruction cost 3 - 12 %.
 // (a macro: the immediate must be a constant where the statement stands -- inside an unrolled loop it is one after unrolling)
+// Two hazards of gfx9 that hipcc resolves for its own instructions and cannot see inside an asm statement (LLVM
+// GCNHazardRecognizer): a VALU write of the data registers of a vector-memory store of more than 8 bytes needs two wait states
+// behind the store -- the trailing s_nop (without it whatever the compiler schedules next may overwrite the first data register
+// while the last lanes are still being read: round 5 found the low dword of four doubles of a tile zeroed that way, in one launch
+// out of a few, after a change elsewhere had moved the instructions behind the last store of a tile); and a vector-memory
+// instruction that reads an SGPR written by a VALU instruction (the base comes from v_readfirstlane) needs five wait states in
+// front -- FE_STORE16_WRITE_THROUGH_FIRST, for the first store of a batch.
 #define FE_STORE16_WRITE_THROUGH(base_uniform, lane_offset, val, imm)                                                     \
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1" ::"v"(lane_offset), "v"(val), "s"(base_uniform), "n"(imm))
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1\n\ts_nop 1" ::"v"(lane_offset), "v"(val), "s"(base_uniform), "n"(imm))
+#define FE_STORE16_WRITE_THROUGH_FIRST(base_uniform, lane_offset, val, imm)                                               \
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1\n\ts_nop 1" ::"v"(lane_offset), "v"(val), "s"(base_uniform), "n"(imm))
 // (no memory clobber: the statement reads registers only, and nothing else touches the output)
 // The chunks of one [rows][NP] output tile (CHUNKS of 16 bytes, INSTR wave-instructions), already in registers, to `op`
 // (wave-uniform): non-temporal, or write-through for the short launches above.
@@ -132,8 +141,10 @@ __device__ __forceinline__ void store_tile_held(double* op, int lane, const v2d 
         op = reinterpret_cast<double*>((unsigned long long)lo | ((unsigned long long)hi << 32));
 #pragma unroll
         for (int c = 0; c < INSTR; ++c)
-            if ((c + 1) * 64 <= CHUNKS || c * 64 + lane < CHUNKS)
-                FE_STORE16_WRITE_THROUGH(op, (unsigned)(lane * 16 + (c >> 2) * 4096), held[c], (c & 3) * 1024);
+            if ((c + 1) * 64 <= CHUNKS || c * 64 + lane < CHUNKS) {
+                if (c == 0) FE_STORE16_WRITE_THROUGH_FIRST(op, (unsigned)(lane * 16), held[c], 0);
+                else FE_STORE16_WRITE_THROUGH(op, (unsigned)(lane * 16 + (c >> 2) * 4096), held[c], (c & 3) * 1024);
+            }
     } else {
 #pragma unroll
         for (int c = 0; c < INSTR; ++c) {

@@ -27,6 +27,8 @@
 // contiguous 16-byte chunks of out[x, e0 + 16 m : e0 + 16 m + 16, :].  Waves never synchronise
 // with each other after the one-time operator staging.
 #pragma once
+#include <type_traits>
+
 #include "fe_common.h"
 #include "fe_generic.h"
 
@@ -279,6 +281,10 @@ __device__ __forceinline__ void grad3d_mfma_body(
     const int64_t tEnd = t_full;
 
     double afrag[G::RT][G::KS];
+    // (one sub-tile per wave tile) stage 1 of the wave's first unit runs with the fragment build: see the prologue
+    constexpr bool kFusedFirst = (M == 1) && !kPrep && !kDyn && (kDbg & ~32) == 0;   // (the dynamic-walk kernels have no registers to spare for it)
+    v4d acc_first[G::RT];
+    bool first_ready = false;
     // experiment (kDbg & 128): the walk covers both halves of the element range at once (see fe_div.h, kDbg & 4)
     const int64_t half_tiles = (nTiles + 1) / 2;
     auto phys = [&](int64_t t) -> int64_t { return (kDbg & 128) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
@@ -320,73 +326,13 @@ __device__ __forceinline__ void grad3d_mfma_body(
             }
         });
     };
-    if constexpr (kPrep) {
-        load_prepared_fragments<G::RT * G::KS>(prep, lane, [&](int f, double v) { afrag[f / G::KS][f % G::KS] = v; });
-        issue_first_units();
-        prepared_fragments_landed();
-        remainder(D);
-    } else {
-        // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
-        stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
-        switch (issue_first_units()) {
-            case 1: wait_vmcnt<G::LOADS + G::U_INSTR>(); break;
-            case 2: wait_vmcnt<2 * G::LOADS>(); break;
-            case 3: wait_vmcnt<G::LOADS>(); break;
-            default: wait_vmcnt<0>(); break;
-        }
-#ifdef FE_EXPERIMENTS
-        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][0] = __builtin_amdgcn_s_memrealtime();
-#endif
-        __syncthreads();
-#ifdef FE_EXPERIMENTS
-        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][1] = __builtin_amdgcn_s_memrealtime();
-#endif
-
-        // ---- A fragments from the staged operator (addresses = row part + column part: the 63
-        //      fragments of p = 4 cost one add and one LDS read each)
-        const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
-        const int gp = n & 3, q = n >> 2;
-        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
-        int joff[G::KS];
-        bool jok[G::KS];
-#pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int j = 4 * ks + g;
-            jok[ks] = j < NP;
-            joff[ks] = (jok[ks] ? j : 0) * jstride;
-        }
-#pragma unroll
-        for (int t = 0; t < G::RT; ++t) {
-            const int s = 4 * t + q;
-            const int r = s % 3, i = G::TG * gp + s / 3;
-            const bool rowok = (s < 3 * G::TG) && (i < NP);
-            const double* row = dl + r * (NP * NP) + (i < NP ? i : 0) * istride;
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                const double v = row[joff[ks]];
-                afrag[t][ks] = (rowok && jok[ks]) ? v : 0.0;
-            }
-        }
-#ifdef FE_EXPERIMENTS
-        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fe_dbg_phase[bid * G::WAVES + wave][2] = __builtin_amdgcn_s_memrealtime();
-        }
-#endif
-        remainder(dl);     // (while the block's copy of the operator is still there)
-        __syncthreads();   // the staging area becomes the waves' output buffers
-#ifdef FE_EXPERIMENTS
-        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][3] = __builtin_amdgcn_s_memrealtime();
-#endif
-    }
-
-
     int dbg_it = 0;   // (experiments build: units done by this wave, for the per-tile stamps)
 #ifdef FE_EXPERIMENTS
     if ((kDbg & 32) && lane < 16) reinterpret_cast<unsigned long long*>(smem + G::LDS_BYTES)[wave * 16 + lane] = 0;
 #endif
     // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
-    auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt) {
+    auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt, auto with_acc) {
+        constexpr bool kHaveAcc = decltype(with_acc)::value;   // stage 1 of this unit is in acc_first already
         FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
         double* out_x[3];
         out_x[0] = grad_plane_out(P, fk, 0);
@@ -397,26 +343,31 @@ __device__ __forceinline__ void grad3d_mfma_body(
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             // ---- stage 1 on sub-tile m
-            double bfrag[G::KS];
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                const int j = 4 * ks + g;
-                const double b = ut[(16 * m + n) * NP + (j < NP ? j : 0)];
-                bfrag[ks] = (j < NP) ? b : 0.0;
-            }
             v4d acc[G::RT];
+            if constexpr (kHaveAcc) {
 #pragma unroll
-            for (int t = 0; t < G::RT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-            if (kDbg & 1) {
-#pragma unroll
-                for (int t = 0; t < G::RT; ++t)
-                    acc[t] = v4d{bfrag[t % G::KS], bfrag[(t + 1) % G::KS], bfrag[(t + 2) % G::KS], afrag[t][0]};
+                for (int t = 0; t < G::RT; ++t) acc[t] = acc_first[t];
             } else {
+                double bfrag[G::KS];
 #pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks)
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const int j = 4 * ks + g;
+                    const double b = ut[(16 * m + n) * NP + (j < NP ? j : 0)];
+                    bfrag[ks] = (j < NP) ? b : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+                if (kDbg & 1) {
 #pragma unroll
                     for (int t = 0; t < G::RT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                        acc[t] = v4d{bfrag[t % G::KS], bfrag[(t + 1) % G::KS], bfrag[(t + 2) % G::KS], afrag[t][0]};
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+                        for (int t = 0; t < G::RT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bfrag[ks], acc[t], 0, 0, 0);
+                }
             }
 
             FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the matrix work is issued
@@ -473,7 +424,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
 
 #ifdef FE_EXPERIMENTS
     unsigned long long c0 = 0, r0 = 0;
-    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     auto write_stamps = [&](int tiles_done) {
         FE_TILE_STAMPS_OUT(kDbg & 32, smem + G::LDS_BYTES, wave, lane, bid * G::WAVES + wave);
         if (!((kDbg & 32) && lane == 0)) return;
@@ -488,85 +438,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
         if (w == 0) { fe_dbg_clock[0] = __builtin_amdgcn_s_memtime() - c0; fe_dbg_clock[1] = t_end - r0; }
     };
 #endif
-    if constexpr (kDyn) {
-        if (dyn && nb == 1) {
-            // ---- walk with a dynamic tail (fe_common.h): static tiles first + k stride below t_static, then tickets.
-            //      Vector-memory ops of an iteration in issue order: [A = ticket for the tile after next] L(next) S(cur);
-            //      every wave has a static first tile (t_static >= number of waves).
-            constexpr int NL = G::LOADS, NS = G::STORES;
-            const int pool = (bid >> 3) & (kTailPools - 1);
-            unsigned* const counter = tail_pool_counters(tail, pool);
-            unsigned* const done = tail_pool_reports(counter);   // the pool's report counter, half a stride behind its tickets
-            // waves of this pool: blocks b with (b / 8) % kTailPools == pool
-            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 +
-                                         (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
-            const unsigned pool_waves = pool_blocks * G::WAVES;
-            auto ticket_tile = [&](unsigned t) -> int64_t { return tail_ticket_tile(t, t_static, pool, tEnd); };
-            auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
-            int64_t cur = tile, nxt = static_next(tile);   // nxt >= 0: requested by the prologue (pre)
-            bool pending = false, reported = false, prev_pre = false, first = true;
-            if (nxt < 0) {   // one static round: the prologue's ticket, behind L(cur)
-                tail_request<0>(counter);
-                pending = true;
-            }
-            int buf = 0, iteration = 0;
-            const bool younger_half = bid >= (nblk + 1) / 2;
-            while (cur >= 0) {
-                balance_priority(younger_half, iteration++);   // dyn
-                bool extra = false;   // one more vector-memory op (ticket or report) issued in this iteration
-                if (pending) {   // the next tile comes from a ticket: younger than it are L(cur) and S(previous)
-                    const unsigned t = first ? tail_wait<0, 0>() : prev_pre ? tail_wait<NS, 0>() : tail_wait<NL + NS, 0>();
-                    nxt = ticket_tile(t);
-                    pending = false;
-                    if (nxt < 0) {   // this wave's pool is empty: stop asking, report
-                        tail_request<1>(done);
-                        reported = true;
-                        extra = true;
-                    }
-                }
-                if (nxt >= 0) {
-                    if (static_next(nxt) < 0) {   // the tile after next is not static
-                        tail_request<0>(counter);
-                        pending = true;
-                        extra = true;
-                    }
-                    if (!pre) {
-                        grad_issue_u<NP, M, kNT>(P.u[0], nxt, lane, lds_addr_uniform(L->u[buf ^ 1]), tload);
-                        grad_issue_j<NP, M, kPlain>(P, E, nxt, lane, lds_addr_uniform(L->j[buf ^ 1]));
-                    }
-                }
-                // wait L(cur): younger are S(previous), the ticket / report, L(next)
-                if (nxt >= 0) {
-                    if (first) { if (extra) wait_vmcnt<NL + 1>(); else wait_vmcnt<NL>(); }
-                    else { if (extra) wait_vmcnt<NS + NL + 1>(); else wait_vmcnt<NS + NL>(); }
-                } else {
-                    if (first) { if (extra) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
-                    else { if (extra) wait_vmcnt<NS + 1>(); else wait_vmcnt<NS>(); }
-                }
-                compute_unit(cur, 0, L->u[buf], L->j[buf]);
-                first = false;
-                prev_pre = pre;
-                pre = false;
-                cur = nxt;
-                buf ^= 1;
-                if (cur >= 0 && !pending) nxt = static_next(cur);
-            }
-            // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch (its own report is
-            // older than its last tile's stores; nobody else touches this pool's counters any more)
-            if (reported) {
-                const unsigned before = tail_wait<NS, 1>();
-                if (before + 1 == pool_waves && lane == 0) {
-                    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#ifdef FE_EXPERIMENTS
-            write_stamps(iteration);
-#endif
-            return;
-        }
-    }
-
     // ---- the quarter tile of this wave (see the top): its loads -- four rows of u (contiguous), nine times four doubles of J, compact
     //      as j[k * 4 + element] -- and, behind the loop, the unit itself
     constexpr int kQuarterChunks = 4 * NP / 2;                             // 16-byte chunks of four rows of u
@@ -581,36 +452,102 @@ __device__ __forceinline__ void grad3d_mfma_body(
             }
         if (lane < 18) glds16(reinterpret_cast<const char*>(P.j[0]) + ((int64_t)(lane >> 1) * E + q_e0) * 8 + (lane & 1) * 16, lds_j);
     };
+    // ---- the walk.  A step has a TOP (the next unit's loads and, under the dynamic walk, the ticket traffic go out; wait for this
+    //      unit's loads) and a BOTTOM (stage 1, stage 2, the transposed stores; advance).  The top of a wave's first step runs in the
+    //      prologue, in front of the fragment build that is fused with that unit's stage 1 (kFusedFirst).
+    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
+    int iteration = 0;
+    // (a) dynamic walk of one field (fe_common.h): static tiles first + k stride below t_static, then tickets.
+    //     Vector-memory ops of an iteration in issue order: [A = ticket for the tile after next] L(next) S(cur);
+    //     every wave has a static first tile (t_static >= number of waves).
+    const bool use_dyn = kDyn && dyn && nb == 1;   // grid-uniform
+    constexpr int NL = G::LOADS, NS = G::STORES;
+    const int pool = (bid >> 3) & (kTailPools - 1);
+    unsigned* const counter = tail_pool_counters(tail, pool);
+    unsigned* const done = tail_pool_reports(counter);   // the pool's report counter, half a stride behind its tickets
+    auto static_next = [&](int64_t t) -> int64_t { return (t < t_static && t + stride < t_static) ? t + stride : -1; };
+    int64_t cur = tile, nxt = -1;   // nxt >= 0 at the start: requested by the prologue (pre)
+    bool pending = false, reported = false, prev_pre = false, dfirst = true;
+    int buf = 0;
+    auto dyn_init = [&]() {   // behind the prologue's loads
+        nxt = static_next(tile);
+        if (nxt < 0) {   // one static round: the prologue's ticket, behind L(cur)
+            tail_request<0>(counter);
+            pending = true;
+        }
+    };
+    auto dyn_top = [&]() {
+        balance_priority(younger_half, iteration++);   // dyn
+        bool extra = false;   // one more vector-memory op (ticket or report) issued in this iteration
+        if (pending) {   // the next tile comes from a ticket: younger than it are L(cur) and S(previous)
+            const unsigned t = dfirst ? tail_wait<0, 0>() : prev_pre ? tail_wait<NS, 0>() : tail_wait<NL + NS, 0>();
+            nxt = tail_ticket_tile(t, t_static, pool, tEnd);
+            pending = false;
+            if (nxt < 0) {   // this wave's pool is empty: stop asking, report
+                tail_request<1>(done);
+                reported = true;
+                extra = true;
+            }
+        }
+        if (nxt >= 0) {
+            if (static_next(nxt) < 0) {   // the tile after next is not static
+                tail_request<0>(counter);
+                pending = true;
+                extra = true;
+            }
+            if (!pre) {
+                grad_issue_u<NP, M, kNT>(P.u[0], nxt, lane, lds_addr_uniform(L->u[buf ^ 1]), tload);
+                grad_issue_j<NP, M, kPlain>(P, E, nxt, lane, lds_addr_uniform(L->j[buf ^ 1]));
+            }
+        }
+        // wait L(cur): younger are S(previous), the ticket / report, L(next)
+        if (nxt >= 0) {
+            if (dfirst) { if (extra) wait_vmcnt<NL + 1>(); else wait_vmcnt<NL>(); }
+            else { if (extra) wait_vmcnt<NS + NL + 1>(); else wait_vmcnt<NS + NL>(); }
+        } else {
+            if (dfirst) { if (extra) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+            else { if (extra) wait_vmcnt<NS + 1>(); else wait_vmcnt<NS>(); }
+        }
+    };
+    auto dyn_bottom = [&](auto with_acc) {
+        compute_unit(cur, 0, L->u[buf], L->j[buf], with_acc);
+        dfirst = false;
+        prev_pre = pre;
+        pre = false;
+        cur = nxt;
+        buf ^= 1;
+        if (cur >= 0 && !pending) nxt = static_next(cur);
+    };
+    // (b) static walk, any number of fields -- and the dynamic walk with b >= 2 fields (units (tile, field), field fastest): the
+    //     ticket for the next tile is asked for at the top of the tile's first field -- in front of the next unit's loads -- and
+    //     read at the top of its last field, where the wait for it (everything but the previous unit's stores) is the wait for
+    //     this unit's loads as well
     int ub = 0, jbuf = 0;     // u buffer toggles per (tile, field) unit, J buffer per tile
     bool first = true;
-    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
-    int iteration = 0, fk = 0;
-    // dynamic walk with b >= 2 fields (units (tile, field), field fastest): the ticket for the next tile is asked for at the top
-    // of the tile's first field -- in front of the next unit's loads -- and read at the top of its last field, where the wait
-    // for it (everything but the previous unit's stores) is the wait for this unit's loads as well
+    int fk = 0;
     const bool dynb = kDyn && dyn && nb >= 2;   // grid-uniform
-    const int poolb = (bid >> 3) & (kTailPools - 1);
-    unsigned* const counterb = tail_pool_counters(tail, poolb);
-    unsigned* const doneb = tail_pool_reports(counterb);
     bool pendingb = false, reportedb = false;
-    while (tile < tEnd) {
+    bool next_new_tile = true;   // (set by the top, used by the bottom)
+    int64_t nt = 0;
+    int nk = 0;
+    auto static_top = [&]() {
         balance_priority(younger_half, iteration++);
         // Vector-memory ops in issue order: L(unit) S(previous unit) [ticket] L(next unit) | wait L(unit).
         // The stores of the previous unit and the loads of the next one are younger than this
         // unit's loads and stay in flight.
-        const bool next_new_tile = (fk + 1 == nb);
-        int64_t nt = next_new_tile ? tile + stride : tile;
-        const int nk = next_new_tile ? 0 : fk + 1;
+        next_new_tile = (fk + 1 == nb);
+        nt = next_new_tile ? tile + stride : tile;
+        nk = next_new_tile ? 0 : fk + 1;
         bool extra = false;   // a ticket or the report goes out at this top
         if constexpr (kDyn) {
             if (dynb) {
                 const bool successor_static = tile < t_static && tile + stride < t_static;
                 if (next_new_tile) {
                     if (pendingb) {
-                        nt = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, poolb, tEnd);
+                        nt = tail_ticket_tile(tail_wait<G::STORES, 0>(), t_static, pool, tEnd);
                         pendingb = false;
                         if (nt < 0) {   // this wave's pool is empty: stop asking, report
-                            tail_request<1>(doneb);
+                            tail_request<1>(done);
                             reportedb = true;
                             extra = true;
                             nt = tEnd;
@@ -619,7 +556,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                         nt = tEnd;   // (cannot happen: a tile whose successor is not static has asked at its first field)
                     }
                 } else if (fk == 0 && !successor_static) {
-                    tail_request<0>(counterb);
+                    tail_request<0>(counter);
                     pendingb = true;
                     extra = true;
                 }
@@ -651,12 +588,191 @@ __device__ __forceinline__ void grad3d_mfma_body(
         }
         first = false;
         pre = false;
-
-        compute_unit(tile, fk, L->u[ub], L->j[jbuf]);
+    };
+    auto static_bottom = [&](auto with_acc) {
+        compute_unit(tile, fk, L->u[ub], L->j[jbuf], with_acc);
         fk = nk;
         tile = nt;
         ub ^= 1;
         if (next_new_tile) jbuf ^= 1;
+    };
+    auto first_top = [&]() {   // (kFusedFirst: from the prologue)
+        if constexpr (kDyn) {
+            if (use_dyn) {
+                dyn_init();
+                dyn_top();
+                return;
+            }
+        }
+        static_top();
+    };
+
+    if constexpr (kPrep) {
+        load_prepared_fragments<G::RT * G::KS>(prep, lane, [&](int f, double v) { afrag[f / G::KS][f % G::KS] = v; });
+        issue_first_units();
+        prepared_fragments_landed();
+        remainder(D);
+    } else {
+        // ---- operator -> LDS (DMA), and behind it the loads of this wave's first two units
+        stage_operator_dma<G::OP_D>(D, lds_addr_uniform(smem + G::IN_BYTES), wave, lane);
+        const int units_issued = issue_first_units();
+        switch (units_issued) {
+            case 1: wait_vmcnt<G::LOADS + G::U_INSTR>(); break;
+            case 2: wait_vmcnt<2 * G::LOADS>(); break;
+            case 3: wait_vmcnt<G::LOADS>(); break;
+            default: wait_vmcnt<0>(); break;
+        }
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+        __syncthreads();
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+        // ---- A fragments from the staged operator (addresses = row part + column part: the 63
+        //      fragments of p = 4 cost one add and one LDS read each)
+        const double* dl = reinterpret_cast<const double*>(smem + G::IN_BYTES);
+        remainder(dl);     // (while the block's copy of the operator is there; in front of the build: few registers are live here)
+        const int gp = n & 3, q = n >> 2;
+        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored as [r][j][i]
+        if constexpr (kFusedFirst) {
+            // One sub-tile per wave tile (p = 4): the build runs INSIDE stage 1 of the wave's first unit.  The fragments of k-step
+            // ks + 1 are read (LDS reads issue beside the wave's own MFMAs; its VALU instructions do not: DESIGN.md section 3h)
+            // while the MFMAs of k-step ks run, so that the matrix pipe starts ~1 us earlier on the older wave of a SIMD and the
+            // younger wave's build no longer crawls beside its partner's matrix phase (3 us at E = 1e5:
+            // profiles/r04/grad_1e5_stamps_and_decomposition.txt).  Only the last row tile and the last k-step hold padding.
+            static_assert(4 * (G::RT - 1) <= 3 * G::TG && 3 * G::TG + (4 * (G::RT - 1) - 1) / 3 < NP && 4 * G::KS - 5 < NP,
+                          "padding rows in the last row tile only, padding columns in the last k-step only");
+            const double* rowp[G::RT];                // row part + this lane's column g; k-step ks adds the (uniform) 4 ks jstride
+            bool rowok_last = true;
+#pragma unroll
+            for (int t = 0; t < G::RT; ++t) {
+                const int s_ = 4 * t + q;
+                const int r = s_ % 3, i = G::TG * gp + s_ / 3;
+                if (t == G::RT - 1) rowok_last = (s_ < 3 * G::TG) && (i < NP);
+                rowp[t] = dl + r * (NP * NP) + (i < NP ? i : 0) * istride + g * jstride;
+            }
+            const bool jok_last = 4 * (G::KS - 1) + g < NP;
+            // (column 4 (KS - 1) + g = NP of the lanes g = 3 is read from inside the block's LDS -- one double behind the row, at most
+            // NP doubles behind the operator, which the output buffers cover -- and replaced by zero)
+            static_assert(4 * G::KS - NP <= 1 && (G::OP_D + NP + 1) * 8 <= G::LDS_BYTES - G::IN_BYTES, "the padding column stays inside the staging area");
+            const int kstep = 4 * jstride;
+            auto read_step = [&](int ks) {
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) afrag[t][ks] = rowp[t][ks * kstep];
+            };
+            auto fix_step = [&](int ks) {   // (compile-time ks: the selects exist for the last row tile and the last k-step only)
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) {
+                    if (t == G::RT - 1 && ks == G::KS - 1) afrag[t][ks] = (rowok_last && jok_last) ? afrag[t][ks] : 0.0;
+                    else if (t == G::RT - 1) afrag[t][ks] = rowok_last ? afrag[t][ks] : 0.0;
+                    else if (ks == G::KS - 1) afrag[t][ks] = jok_last ? afrag[t][ks] : 0.0;
+                }
+            };
+            if (units_issued != 0) {
+                read_step(0);
+                first_top();   // the top of this wave's first step: ends with its first unit landed
+                const double* ub0 = L->u[0] + n * NP + g;   // B operand of k-step ks: u[e = n][4 ks + g]
+                double bnext = ub0[0];
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t) acc_first[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    double bcur = bnext;
+                    if (ks + 1 < G::KS) {
+                        read_step(ks + 1);
+                        bnext = (ks + 1 == G::KS - 1) ? ub0[jok_last ? 4 * (ks + 1) : 0] : ub0[4 * (ks + 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    fix_step(ks);
+                    if (ks == G::KS - 1) bcur = jok_last ? bcur : 0.0;
+#pragma unroll
+                    for (int t = 0; t < G::RT; ++t)
+                        acc_first[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][ks], bcur, acc_first[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                first_ready = true;
+            } else {   // a wave without a tile
+#pragma unroll
+                for (int t = 0; t < G::RT; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < G::KS; ++ks) afrag[t][ks] = 0.0;
+            }
+        } else {
+            int joff[G::KS];
+            bool jok[G::KS];
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const int j = 4 * ks + g;
+                jok[ks] = j < NP;
+                joff[ks] = (jok[ks] ? j : 0) * jstride;
+            }
+#pragma unroll
+            for (int t = 0; t < G::RT; ++t) {
+                const int s = 4 * t + q;
+                const int r = s % 3, i = G::TG * gp + s / 3;
+                const bool rowok = (s < 3 * G::TG) && (i < NP);
+                const double* row = dl + r * (NP * NP) + (i < NP ? i : 0) * istride;
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const double v = row[joff[ks]];
+                    afrag[t][ks] = (rowok && jok[ks]) ? v : 0.0;
+                }
+            }
+        }
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fe_dbg_phase[bid * G::WAVES + wave][2] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+        __syncthreads();   // the staging area becomes the waves' output buffers
+#ifdef FE_EXPERIMENTS
+        if ((kDbg & 32) && lane == 0 && bid * G::WAVES + wave < 4096) fe_dbg_phase[bid * G::WAVES + wave][3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+
+
+#ifdef FE_EXPERIMENTS
+    if (kDbg & 32) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // ---- walk
+    if constexpr (kDyn) {
+        if (use_dyn) {
+            if constexpr (kFusedFirst) {
+                if (first_ready) dyn_bottom(std::true_type{});
+                else dyn_init();
+            } else {
+                dyn_init();
+            }
+            while (cur >= 0) {
+                dyn_top();
+                dyn_bottom(std::false_type{});
+            }
+            // the last wave of a pool to report leaves the pool's two counters zeroed for the next launch (its own report is
+            // older than its last tile's stores; nobody else touches this pool's counters any more)
+            if (reported) {
+                // waves of this pool: blocks b with (b / 8) % kTailPools == pool
+                const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
+                const unsigned before = tail_wait<NS, 1>();
+                if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
+                    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#ifdef FE_EXPERIMENTS
+            write_stamps(iteration);
+#endif
+            return;
+        }
+    }
+    if constexpr (kFusedFirst) {
+        if (first_ready) static_bottom(std::true_type{});
+    }
+    while (tile < tEnd) {
+        static_top();
+        static_bottom(std::false_type{});
     }
     if constexpr (kPlain && !kPrep && M == 1) {
         if (q_e0 >= 0) {
@@ -705,11 +821,11 @@ __device__ __forceinline__ void grad3d_mfma_body(
     }
     if constexpr (kDyn) {
         if (reportedb) {   // the last wave of a pool to report leaves the pool's counters zeroed (younger than the report: this unit's stores)
-            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * poolb));
+            const unsigned pool_blocks = (nblk / (8 * kTailPools)) * 8 + (unsigned)max(0, min(8, (int)(nblk % (8 * kTailPools)) - 8 * pool));
             const unsigned before = tail_wait<G::STORES, 1>();
             if (before + 1 == pool_blocks * G::WAVES && lane == 0) {
-                __hip_atomic_store(counterb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(doneb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
