@@ -463,7 +463,8 @@ int64_t fe_set_div_interleave(int64_t tiles);
 int fe_set_div_quarter_tail(int32_t on);
 /* The same for grad launches of one field on the static walk (tetrahedra p = 4): the four elements of a quarter tile run stage 1
  * on v_mfma_f64_4x4x4_4b with the fragments of the full tiles and stage 2 through LDS (default on; also
- * FEINSUM_GRAD_QUARTER_TAIL).  Returns the previous setting.  Bitwise the results of the full tiles. */
+ * FEINSUM_GRAD_QUARTER_TAIL; a value n >= 4 widens the rule from an eighth to 1/n of a round, for measurements: a quarter of a
+ * round loses 1 - 5 %).  Returns the previous setting.  Bitwise the results of the full tiles. */
 int fe_set_grad_quarter_tail(int32_t on);
 /* Phase priorities in the eight-wave kernels of tetrahedra p = 5 (grad, div): the waves' f64 VALU phases at raised issue
  * priority, their matrix phases at priority 0 (default off: -1 % for div at E >= 1e6, +-1 % for grad; also
