@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 final measurements in one GPU call: outputs under gpurun_out/final_r05/ (copied to profiles/r05/ afterwards).
 out=gpurun_out/final_r05; mkdir -p $out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -rs > $out/pytest_gpu.log 2>&1; tail -6 $out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
 for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_grad_driver$i.json 2>> $out/bench.err; done
 for w in div facemass graddiv pipeline; do python3 bench.py --workload $w --no-cpu-baseline > $out/bench_$w.json 2>> $out/bench.err; done
