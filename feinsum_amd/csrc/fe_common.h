@@ -111,8 +111,9 @@ constexpr long long kWriteThroughOutputBytes = 128ll << 20;
 // s_setprio where it would matter: beside a partner's pure MFMA stream a wave's VALU instructions take 8.8 cycles each at
 // either priority and the MFMA stream is not slowed (profiles/r05/mfma_arbiter_two_waves.txt).
 constexpr int kOpPhasePriority = 64;
-// kOpQuarterTail (round 5; the interleaved div kernel under the static walk): the tiles behind the last full round -- fewer than
-// a quarter round of them -- are processed as QUARTER tiles of four elements, one per wave, on v_mfma_f64_4x4x4_4b (fe_div.h).
+// kOpQuarterTail (round 5; the interleaved div kernel and the grad kernel under the static walk, one field): the tiles behind the
+// last full round -- at most an eighth of a round of them -- are processed as QUARTER tiles of four elements, one per wave, on
+// v_mfma_f64_4x4x4_4b (fe_div.h, fe_grad.h).
 constexpr int kOpQuarterTail = 128;
 // One 16-byte write-through store per lane, in the addressing form the compiler gives its own stores (wave-uniform base in
 // SGPRs + one 32-bit lane offset + immediate): with a 64-bit VGPR address per store the same instruction cost 3 - 12 %.

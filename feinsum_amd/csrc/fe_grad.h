@@ -26,6 +26,9 @@
 // results are transposed through wave-private LDS buffers so that the global stores write
 // contiguous 16-byte chunks of out[x, e0 + 16 m : e0 + 16 m + 16, :].  Waves never synchronise
 // with each other after the one-time operator staging.
+// Round 5 (one sub-tile per wave tile, i.e. p = 4): the A fragments are read from the staged operator INSIDE stage 1 of a
+// wave's first tile (kFusedFirst: the static-walk kernels), and a ragged last round of a short launch runs as quarter tiles
+// of four elements on v_mfma_f64_4x4x4_4b (kOpQuarterTail) -- both in grad3d_mfma_body.
 #pragma once
 #include <type_traits>
 
