@@ -680,15 +680,16 @@ def main() -> None:
                 "what": "one allocation per array; outputs from the split allocator (fe_split_alloc: 4 MiB pieces alternating between "
                         "two classes of physical memory, classified in groups of 128 MiB by a two-stream write probe; no arena, no "
                         "timing scan)",
-                "output_pieces_by_class": [i.get("pieces_by_class", "torch allocation (below 8 MiB)") for i in infos],
+                "output_pieces_by_class": [i.get("pieces_by_class", "torch allocation (below 8 MiB, or refused by the allocator: no second class found)") for i in infos],
                 "output_bytes": sum(int(t.numel()) * t.element_size() for od in out_dicts for t in od.values()),
                 "output_mapped_bytes": sum(i.get("mapped_bytes", 0) for i in infos),
                 "allocator_ms": round(pool["setup_ms"] + pool["alloc_ms_total"], 3),
                 "inputs_and_outputs_ready_ms": round(t_alloc, 1),
                 "pool": {k: pool.get(k) for k in ("classes", "pieces_created", "groups_probed", "probes", "probe_ms", "spacers_created", "spacer_bytes_peak", "spacer_ms",
-                                                    "search_ms", "search_ms_budget", "release_ms", "groups_discarded", "unsplit_arrays", "pooled_bytes", "walk_gave_up")},
-                # an output whose pieces are all of ONE class runs like an ordinary allocation: not a split-placement result
-                "degraded": bool(pool.get("unsplit_arrays", 0)),
+                                                    "search_ms", "search_ms_budget", "release_ms", "groups_discarded", "unsplit_arrays", "unsplit_refused", "pooled_bytes", "walk_gave_up")},
+                # an output the allocator could not split (no second class of physical memory within its budget) is an ordinary torch
+                # allocation (round 5; round 4 handed out an array of ONE class): not a split-placement result
+                "degraded": bool(pool.get("unsplit_arrays", 0) or pool.get("unsplit_refused", 0)),
             }
     else:
         stages, out_dicts = separate_allocations()
@@ -723,7 +724,7 @@ def main() -> None:
     per_rank = gather_rank_reports({"elements": E, "kernel_ms": timed["local_kernel"] / args.steps * 1e3, "wall_ms": timed["local_wall"] / args.steps * 1e3,
                                     "placement_mode": ("split" if placement_report.get("mode") == "split" else
                                                        "separate (split allocator failed)" if "fallback" in placement_report else "separate"),
-                                    "unsplit_arrays": pool_r.get("unsplit_arrays", 0) or 0, "allocator_ms": placement_report.get("allocator_ms", 0.0),
+                                    "unsplit_arrays": (pool_r.get("unsplit_arrays", 0) or 0) + (pool_r.get("unsplit_refused", 0) or 0), "allocator_ms": placement_report.get("allocator_ms", 0.0),
                                     "search_ms": pool_r.get("search_ms", 0.0) or 0.0, "release_ms": pool_r.get("release_ms", 0.0) or 0.0}, device)
 
     # the reference's own protocol on the same bound launch (every rank, no barrier inside)

@@ -87,6 +87,7 @@ constexpr int kSplitProbePasses = 2;                // the probe writes 2 stream
 constexpr double kSplitSameBelowGBps = 5950.0;
 constexpr double kSplitOtherAboveGBps = 6400.0;
 constexpr size_t kSplitSpacerUnit = 32 * kSplitMiB;   // see acquire()
+constexpr int kSplitNoSecondClass = -1000;             // (internal: acquire() found no second class and unsplit arrays are refused)
 constexpr size_t kSplitMinCollect = 128;               // pieces (512 MiB) of a run's class collected before the search skips ahead: see acquire()
 constexpr size_t kSplitAnchorBytes = 256 * kSplitMiB; // a class's reference region: ONE handle (one buddy block: pure)
 constexpr int kSplitMaxClasses = 3;                 // three superclasses on MI355X (a fourth "class" would be a misreading)
@@ -145,6 +146,14 @@ class SplitPool {
         // pool may skip through its share of the free memory only
         if (const char* sh = getenv("FEINSUM_SPLIT_SHARE")) share_ = std::max(1, atoi(sh));
         if (const char* gib = getenv("FEINSUM_SPLIT_VA_GIB")) va_cap_ = (size_t)(atof(gib) * 1024.0) * kSplitMiB;
+        // An array whose pieces would all come from ONE class (no second class within the search budget) is the worst placement
+        // there is -- every write stream of the launch in one class, 5.2 TB/s -- and worse than what an ordinary allocator gives
+        // on average (round 5, one box: grad at E = 8e6 0.694 of the roofline in such an array, 0.797 in a torch array).  The
+        // allocator therefore REFUSES it (FE_EUNSUPPORTED: the caller allocates ordinarily; feinsum_amd.placement does) unless
+        // $FEINSUM_SPLIT_UNSPLIT=1 asks for round 4's behaviour.  $FEINSUM_SPLIT_ONE_CLASS=1: a test hook -- the pool behaves as
+        // if the device offered one class only.
+        if (const char* u = getenv("FEINSUM_SPLIT_UNSPLIT")) allow_unsplit_ = atoi(u) != 0;
+        if (const char* o = getenv("FEINSUM_SPLIT_ONE_CLASS")) force_one_class_ = atoi(o) != 0;
         // the anchor of class 0: ONE handle of 256 MiB (a single block of the driver's allocator, hence of one class --
         // a group of 32 small handles may straddle two runs, and an impure anchor makes every later reading ambiguous:
         // profiles/r03/split_alloc_check_v10_group_anchors_impure.txt); it stays mapped for the life of the process
@@ -181,7 +190,13 @@ class SplitPool {
         if (n_full) {
             // two classes with ceil(n / 2) free pieces each, so that either may take the even positions; the lower class
             // id takes them in even allocations and the odd positions in odd ones
-            if (int rc = acquire((n_full + 1) / 2, &cls[0], &cls[1])) return rc;
+            if (int rc = acquire((n_full + 1) / 2, &cls[0], &cls[1])) {
+                if (rc != kSplitNoSecondClass) return rc;
+                ++unsplit_refused_;
+                return fail(FE_EUNSUPPORTED, "split allocator: no second class of physical memory within the search budget -- an array of one "
+                                             "class would be the worst placement there is: allocate this array ordinarily (FEINSUM_SPLIT_UNSPLIT=1 "
+                                             "hands it out anyway)");
+            }
             if (cls[0] > cls[1]) std::swap(cls[0], cls[1]);
             if (orientation_++ & 1) std::swap(cls[0], cls[1]);
         }
@@ -265,11 +280,11 @@ class SplitPool {
         return snprintf(buf, n,
                         "{\"ready\": %s, \"classes\": %zu, \"free_pieces\": %s, \"pooled_bytes\": %zu, \"live_bytes\": %zu, "
                         "\"live_arrays\": %zu, \"pieces_created\": %zu, \"groups_probed\": %zu, \"probes\": %zu, \"spacer_bytes_peak\": %zu, "
-                        "\"spacers_created\": %zu, \"spacer_ms\": %.1f, \"probe_ms\": %.1f, \"search_ms\": %.1f, \"search_ms_budget\": %.0f, \"release_ms\": %.1f, \"groups_discarded\": %zu, \"unsplit_arrays\": %zu, \"setup_ms\": %.3f, \"alloc_ms_total\": %.3f, "
+                        "\"spacers_created\": %zu, \"spacer_ms\": %.1f, \"probe_ms\": %.1f, \"search_ms\": %.1f, \"search_ms_budget\": %.0f, \"release_ms\": %.1f, \"groups_discarded\": %zu, \"unsplit_arrays\": %zu, \"unsplit_refused\": %zu, \"setup_ms\": %.3f, \"alloc_ms_total\": %.3f, "
                         "\"same_class_below_gbps\": %.0f, \"walk_gave_up\": %s, \"piece_mib\": %zu, \"group_mib\": %zu, "
                         "\"address_space_reserved\": %zu, \"address_space_cap\": %zu, \"last_probes_gbps\": \"%s\"}",
                         ready_ ? "true" : "false", free_.size(), fr.c_str(), pooled * kSplitPiece, live_bytes_, live_.size(),
-                        pieces_created_, groups_probed_, probes_, spacer_bytes_peak_, spacers_created_, spacer_ms_, probe_ms_, search_ms_, search_ms_budget_, release_ms_, groups_discarded_, unsplit_arrays_, setup_ms_,
+                        pieces_created_, groups_probed_, probes_, spacer_bytes_peak_, spacers_created_, spacer_ms_, probe_ms_, search_ms_, search_ms_budget_, release_ms_, groups_discarded_, unsplit_arrays_, unsplit_refused_, setup_ms_,
                         alloc_ms_total_, same_below_gbps_, walk_gave_up_ ? "true" : "false", kSplitPiece / kSplitMiB,
                         kSplitGroupBytes / kSplitMiB, va_reserved_, va_cap_, last_probes_.c_str());
     }
@@ -283,8 +298,12 @@ class SplitPool {
         const double t0 = split_now_ms();
         reserve_pieces_ = (bytes / kSplitPiece + 1) / 2 + 1;
         int ca = -1, cb = -1;
-        const int rc = acquire(reserve_pieces_, &ca, &cb);
+        int rc = acquire(reserve_pieces_, &ca, &cb);
         alloc_ms_total_ += split_now_ms() - t0;
+        if (rc == kSplitNoSecondClass) {   // (an announcement only: the allocations that follow are refused one by one)
+            reserve_pieces_ = 0;
+            rc = FE_OK;
+        }
         return rc;
     }
 
@@ -329,6 +348,8 @@ class SplitPool {
     unsigned orientation_ = 0;
     int last_cls_ = 0;                 // class of the group created last (the driver hands out long runs of one class)
     bool walk_gave_up_ = false;        // a search for a second class ran out of budget: not repeated until fe_split_trim
+    bool allow_unsplit_ = false, force_one_class_ = false;   // $FEINSUM_SPLIT_UNSPLIT, $FEINSUM_SPLIT_ONE_CLASS (ensure_ready)
+    size_t unsplit_refused_ = 0;       // arrays refused because they would have been of one class
     size_t reserve_pieces_ = 0;        // pieces per class announced by reserve() and not handed out yet
     std::string last_probes_;
 
@@ -535,7 +556,7 @@ class SplitPool {
                 if (c1 < 0 || free_[c].size() > free_[c1].size()) { c2 = c1; c1 = c; }
                 else if (c2 < 0 || free_[c].size() > free_[c2].size()) c2 = c;
             }
-            if (c1 >= 0 && c2 >= 0 && free_[c2].size() >= need) { *a = c1; *b = c2; return true; }
+            if (!force_one_class_ && c1 >= 0 && c2 >= 0 && free_[c2].size() >= need) { *a = c1; *b = c2; return true; }
             return false;
         };
         const size_t collect = std::max(kSplitMinCollect, reserve_pieces_);   // of the current run's class, before skipping
@@ -614,7 +635,15 @@ class SplitPool {
         if (rc != FE_OK) return rc;
         if (pick(ca, cb)) return FE_OK;
         walk_gave_up_ = true;
-        // no second class within the budget: every piece from the fullest class
+        if (!allow_unsplit_) {   // (what the search collected of the one class stays pooled up to half the pool's bound)
+            for (auto& list : free_)
+                while (list.size() > max_pooled_pieces_ / 2) {
+                    (void)hipMemRelease(list.back().handle);
+                    list.pop_back();
+                }
+            return kSplitNoSecondClass;
+        }
+        // $FEINSUM_SPLIT_UNSPLIT=1 -- no second class within the budget: every piece from the fullest class
         int c1 = 0;
         for (int c = 1; c < (int)free_.size(); ++c)
             if (free_[c].size() > free_[c1].size()) c1 = c;

@@ -525,7 +525,9 @@ def _allocate_output(shape: Tuple[int, ...], dtype: Any, device: Any, transform:
         # happen inside a stream capture -- torch's allocator knows how to allocate for a graph
         return torch.empty(shape, dtype=dtype, device=device), "torch (stream capture in progress)"
     try:
-        return placement.empty(shape, dtype, device), "split"
+        t = placement.empty(shape, dtype, device)
+        # (the allocator refuses an array that would be of one class of physical memory: placement.empty then allocates ordinarily)
+        return t, "split" if placement.is_split(t) else "torch (the split allocator found no second class of physical memory)"
     except (RuntimeError, HipLibraryError) as exc:
         logger.warning("split allocator not available (%s); the output is an ordinary allocation", str(exc)[:160])
         return torch.empty(shape, dtype=dtype, device=device), f"torch (split allocator failed: {str(exc)[:120]})"
@@ -661,7 +663,7 @@ def timeit_details(einsum: BatchedEinsum, *, transform: Any = None, cq: Any = No
                 out_dict = generate_out_arrays(q, einsum, long_dim_length, split=True)
             infos = {n: placement.split_info(t) for n, t in out_dict.items()}
             report = {"mode": "split", "outputs": {n: ({"pieces_by_class": i["pieces_by_class"], "first_pieces": i["first_pieces"]} if i
-                                                      else "torch allocation (below 8 MiB)") for n, i in infos.items()},
+                                                      else "torch allocation (below 8 MiB, or no second class of physical memory found)") for n, i in infos.items()},
                       "alloc_ms": round(sum(i.get("alloc_ms", 0.0) for i in infos.values()), 3)}
         except (RuntimeError, HipLibraryError) as exc:     # the allocator could not serve: the reference's protocol, and say so
             logger.warning("split allocator not available (%s); timing torch allocations", str(exc)[:160])

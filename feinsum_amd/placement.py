@@ -169,11 +169,33 @@ def empty(shape: Sequence[int], dtype: Any = None, device: Any = None, *, writte
     if not written or dev.type != "cuda" or nbytes < SPLIT_MIN_BYTES:
         return torch.empty(shape, dtype=dtype, device=dev)
     with torch.cuda.device(dev):
-        buf = _SplitBuffer(nbytes, dev.index)
+        try:
+            buf = _SplitBuffer(nbytes, dev.index)
+        except NotImplementedError as exc:
+            # the allocator refuses an array whose pieces would all be of ONE class (no second class of physical memory within its
+            # search budget: fe_split_alloc, FE_EUNSUPPORTED) -- the worst placement there is; an ordinary allocation is better
+            # on average.  Counted: ``ordinary_fallbacks()``, and ``split_stats()["unsplit_refused"]``
+            global _ordinary_fallbacks
+            _ordinary_fallbacks += 1
+            _log.info("split allocator: %s -- torch.empty for %d bytes", str(exc)[:120], nbytes)
+            return torch.empty(shape, dtype=dtype, device=dev)
         flat = torch.as_tensor(buf, device=dev)
     if flat.data_ptr() != buf.ptr:
         raise RuntimeError("torch copied the split allocator's array instead of wrapping it")
     return flat.view(dtype).view(shape)
+
+
+_ordinary_fallbacks = 0
+
+
+def ordinary_fallbacks() -> int:
+    """How many arrays of :func:`empty` this process took from torch because the split allocator refused them."""
+    return _ordinary_fallbacks
+
+
+def is_split(tensor: Any) -> bool:
+    """Whether *tensor* lies in an array of the split allocator."""
+    return bool(split_info(tensor))
 
 
 def zeros(shape: Sequence[int], dtype: Any = None, device: Any = None, *, written: bool = True) -> Any:

@@ -325,8 +325,11 @@ int fe_kernel_resources(char* buf, size_t buf_len);
  *                   in order of discovery), "first_pieces": the classes of the first 16 pieces, "tail_bytes": the last,
  *                   unclassified handle, "alloc_ms"}
  *   fe_split_stats  JSON about the current device's pool: classes seen, free pieces per class, pieces created, groups
- *                   probed, spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_arrays" counts
- *                   arrays that had to take all pieces from one class (no second class found within the budget)
+ *                   probed, spacer bytes used to skip runs of one class, milliseconds spent; "unsplit_refused" counts
+ *                   the arrays fe_split_alloc REFUSED (FE_EUNSUPPORTED) because no second class was found within the
+ *                   budget: all pieces from one class is the worst placement there is, worse on average than an ordinary
+ *                   allocation -- allocate such an array ordinarily (round 5; FEINSUM_SPLIT_UNSPLIT=1 restores round 4's
+ *                   behaviour, counted in "unsplit_arrays")
  *   fe_split_reserve announces the total size of the arrays about to be allocated: half of it is collected of each of two
  *                   classes at once, while the search through the driver's memory is still inside the first class (arrays
  *                   allocated one by one otherwise take only what each needs -- at least 512 MiB per class are collected

@@ -1,9 +1,13 @@
 """feinsum_amd.placement: the placement modes of timeit / evaluate (CPU) and the split allocator on the device."""
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from feinsum_amd import placement
+
+ROOT = Path(__file__).resolve().parents[1]
 
 MIB = placement.MIB
 
@@ -256,3 +260,48 @@ def test_evaluate_without_out_dict_recycles_its_outputs():
     assert torch.equal(outs_c[0], ref)
     del out, outs, outs_c, bound, bound_c, graph
     placement.recycle_trim(0)
+
+
+@pytest.mark.gpu
+def test_an_array_of_one_class_is_refused_and_allocated_ordinarily(tmp_path):
+    """Round 5: when the allocator finds no second class of physical memory within its budget it REFUSES the array (an array
+    whose pieces are all of one class is the worst placement there is: every write stream in one class) and
+    ``placement.empty`` allocates ordinarily -- ``evaluate`` keeps working and says what it got.  ``FEINSUM_SPLIT_UNSPLIT=1``
+    restores the array of one class.  In a fresh process each (the pool reads its knobs once; ``FEINSUM_SPLIT_ONE_CLASS=1``
+    makes it behave as if the device offered one class)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import dg
+import feinsum_amd as f
+from feinsum_amd import placement
+t = placement.empty((3, 200_000, 35), torch.float64, "cuda:0")
+stats = placement.split_stats("cuda:0")
+expr = dg.grad()
+E = 200_000
+g = torch.Generator(device="cuda").manual_seed(1)
+dev = {n: torch.rand(tuple(E if isinstance(d, f.SizeParam) else int(d) for d in expr.arg_to_shape[n]), dtype=torch.float64, device="cuda", generator=g)
+       for n in sorted(expr.all_args)}
+out = f.evaluate(expr, 0, dev, wait=True)["_fe_out"]
+ref = f.evaluate(expr, 0, dev, wait=True, transform={"placement": "separate"})["_fe_out"]
+print(json.dumps({"is_split": placement.is_split(t), "info": placement.split_info(t), "refused": stats["unsplit_refused"], "unsplit": stats["unsplit_arrays"],
+                  "fallbacks": placement.ordinary_fallbacks(), "same": bool(torch.equal(out, ref)), "out_is_split": placement.is_split(out)}))
+""" % (str(ROOT), str(ROOT / "tests"))
+    results = {}
+    for unsplit in ("0", "1"):
+        env = dict(os.environ, FEINSUM_SPLIT_ONE_CLASS="1", FEINSUM_SPLIT_UNSPLIT=unsplit, FEINSUM_SPLIT_SEARCH_MS="300", FEINSUM_SPLIT_SEARCH_GIB="2")
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        results[unsplit] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    refused, handed = results["0"], results["1"]
+    assert not refused["is_split"] and refused["refused"] >= 1 and refused["unsplit"] == 0 and refused["fallbacks"] >= 1, refused
+    assert refused["same"] and not refused["out_is_split"], refused
+    assert handed["is_split"] and handed["unsplit"] >= 1 and handed["refused"] == 0 and handed["same"], handed
+    by_class = [c for c in handed["info"]["pieces_by_class"] if c]
+    assert len(by_class) == 1, handed["info"]
