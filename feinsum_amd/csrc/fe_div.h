@@ -142,6 +142,17 @@ __device__ __forceinline__ void div3d_mfma_body(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;
     const int n = lane & 15, g = lane >> 4;
+    // Experiment switches (the `kDbg` template constant): experiments build only (tools/build_experiments.sh); in the product each
+    // of them is the constant `false`.
+#ifdef FE_EXPERIMENTS
+    constexpr bool x_no_mfma = (kDbg & 1) != 0, x_no_stores = (kDbg & 2) != 0, x_reg_prefetch = (kDbg & 4) != 0, x_no_loads = (kDbg & 8) != 0,
+                   x_early_request = (kDbg & 16) != 0, x_one_plane = (kDbg & 32) != 0, x_lds_ticket = (kDbg & 64) != 0, x_stamps = (kDbg & 128) != 0;
+#else
+    static_assert(kDbg == 0, "experiment flags: experiments build only");
+    constexpr bool x_no_mfma = false, x_no_stores = false, x_reg_prefetch = false, x_no_loads = false, x_early_request = false, x_one_plane = false,
+                   x_lds_ticket = false, x_stamps = false;
+#endif
+    (void)x_stamps; (void)x_one_plane; (void)x_lds_ticket; (void)x_early_request; (void)x_reg_prefetch; (void)x_no_mfma; (void)x_no_stores; (void)x_no_loads;
 
     // ---- A fragments from the LDS-staged operator.  16x16x4: lane (g, n) supplies
     //      A[row 16t + n][k = g];  4x4x4_4b group q: lane (g, n) supplies block n/4, row
@@ -257,7 +268,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         const char* ub = reinterpret_cast<const char*>(field_in(P, fk)) + e0 * (NP * 8);
         if (tload) {   // (fe_common.h, kOpLoadsTemporal: one scalar branch for the whole unit)
 #pragma unroll
-            for (int x = 0; x < ((kDbg & 32) ? 1 : G::NPLANES); ++x) {   // (kDbg & 32, experiments build: one plane only -- timing, wrong results)
+            for (int x = 0; x < (x_one_plane ? 1 : G::NPLANES); ++x) {   // (x_one_plane, experiments build: timing, wrong results)
                 const char* up = ub + (int64_t)x * E * (NP * 8);
 #pragma unroll
                 for (int c = 0; c < G::P_INSTR; ++c)
@@ -550,13 +561,13 @@ __device__ __forceinline__ void div3d_mfma_body(
         //      the partners of a SIMD cannot fall into step), and the next unit requested ahead of the last plane's
         //      stores -- 0.390-0.398 ms against 0.375-0.386 for this loop: neither helps.  The per-wave chain
         //      load -> MFMAs -> three planes through the one buffer is what binds (p = 5).
-        constexpr bool kTicket = (kDbg & 64) != 0, kEarly = (kDbg & 16) != 0;
+        constexpr bool kTicket = x_lds_ticket, kEarly = x_early_request;
         // kRegPre (round 3): the NEXT unit's u tile and J rows are fetched into REGISTERS right after this unit's B values
         // have left the buffer -- 14 + 4 doubles per lane, in flight during the 210 MFMAs -- and written into the (one)
         // tile buffer after this unit's planes have gone out through it.  The LDS-DMA flavour can only ask for the next
         // tile once that buffer is free, i.e. after the stores, and then waits at the top of the loop for the loads AND,
         // through vmcnt(0), for those stores.
-        constexpr bool kRegPre = (kDbg & 4) != 0;
+        constexpr bool kRegPre = x_reg_prefetch;
         v2d nxt_u[G::P_INSTR], nxt_j[G::J_INSTR > 0 ? G::J_INSTR : 1];
         auto load_regs = [&](int64_t t, int f_, bool with_j) {
             const int64_t e0 = t * G::TEL;
@@ -613,7 +624,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         unsigned long long dw = 0, dm = 0, de = 0, dn = 0;
         const unsigned long long dstart = (kDbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
-        if (tile < tEnd && !(kDbg & 8)) {
+        if (tile < tEnd && !x_no_loads) {
             if constexpr (kRegPre) { load_regs(tile, 0, true); regs_to_lds(true); }
             else issue_loads(tile, 0, true);
         }
@@ -657,7 +668,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq) asm volatile("" : "+v"(bf[jq]));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (nt < tEnd && !(kDbg & 8)) load_regs(nt, nk, next_new_tile);
+                if (nt < tEnd && !x_no_loads) load_regs(nt, nk, next_new_tile);
             }
             v4d acc[NC][G::BT > 0 ? G::BT : 1];
             double accs[NC][G::NS > 0 ? G::NS : 1];
@@ -668,7 +679,7 @@ __device__ __forceinline__ void div3d_mfma_body(
 #pragma unroll
                 for (int q = 0; q < G::NS; ++q) accs[r][q] = 0.0;
             }
-            if (kDbg & 1) {     // experiment: no MFMAs (the B values stay live)
+            if (x_no_mfma) {     // experiment: no MFMAs (the B values stay live)
                 double sum = 0.0;
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq) sum += bf[jq];
@@ -733,12 +744,12 @@ __device__ __forceinline__ void div3d_mfma_body(
                                   ? *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc)) : v2d{0.0, 0.0};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // plane x has left the buffer
-                if (!kRegPre && kEarly && x == ND - 1 && nt < tEnd && !(kDbg & 8)) { issue_loads(nt, nk, next_new_tile); requested = true; }
+                if (!kRegPre && kEarly && x == ND - 1 && nt < tEnd && !x_no_loads) { issue_loads(nt, nk, next_new_tile); requested = true; }
 #pragma unroll
                 for (int c = 0; c < G::SUB_INSTR; ++c) {
                     const int qc = c * 64 + lane;
                     if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
-                        if (kDbg & 2) { if (held[c][0] == 1.2345e-300) op[2 * qc] = held[c][1]; }   // experiment: no stores
+                        if (x_no_stores) { if (held[c][0] == 1.2345e-300) op[2 * qc] = held[c][1]; }   // experiment: no stores
                         else __builtin_nontemporal_store(held[c], reinterpret_cast<v2d*>(op + 2 * qc));
                     }
                 }
@@ -755,8 +766,8 @@ __device__ __forceinline__ void div3d_mfma_body(
                 }
             }
             if constexpr (kRegPre) {
-                if (nt < tEnd && !(kDbg & 8)) regs_to_lds(next_new_tile);   // the planes have left the buffer: the next unit moves in
-            } else if (!requested && nt < tEnd && !(kDbg & 8)) {
+                if (nt < tEnd && !x_no_loads) regs_to_lds(next_new_tile);   // the planes have left the buffer: the next unit moves in
+            } else if (!requested && nt < tEnd && !x_no_loads) {
                 issue_loads(nt, nk, next_new_tile);   // (MODE 5: last plane not asked for)
             }
 #ifdef FE_EXPERIMENTS
@@ -802,7 +813,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             const int idx = threadIdx.x + k * G::THREADS;
             held[k] = idx < G::ASMALL_D ? ps[idx] : 0.0;
         }
-        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+        if (tile < tEnd && !x_no_loads) issue_loads(tile, 0, true);
         prepared_fragments_landed();
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
@@ -811,7 +822,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         }
         __syncthreads();   // the table of the 4-row groups is complete
     } else {
-        if (tile < tEnd && !(kDbg & 8)) issue_loads(tile, 0, true);
+        if (tile < tEnd && !x_no_loads) issue_loads(tile, 0, true);
     }
     // ---- the quarter tile of this wave (see above): loads, and the unit itself
     bool q_issued = false;
@@ -907,10 +918,10 @@ __device__ __forceinline__ void div3d_mfma_body(
         int64_t nt = next_new_tile ? tile + stride : tile;
         const int nk = next_new_tile ? 0 : fk + 1;
         // issue order: ... L(unit) [MFMAs(unit-1)] S(unit-1) | wait L(unit): the previous unit's stores are younger
-        if (first || (kDbg & 10)) wait_vmcnt<0>();
+        if (first || x_no_stores || x_no_loads) wait_vmcnt<0>();
         else wait_vmcnt<G::STORES>();
         first = false;
-        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
+        FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
         if constexpr (kIlv) {
             // ---- interleaved form.  The f64 MFMAs run on the vector f64 datapath: beside its partner's matrix phase a wave's
             //      81 f64 VALU instructions of the B build only get the slots between two 64-cycle MFMAs, and the build takes
@@ -919,7 +930,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             //      the wave's own stream (a wave's own VALU instruction costs its 4-5 cycles behind its own MFMA, no more), so a
             //      tile is ONE phase of MFMAs and VALU work and the two waves of a SIMD simply share the pipe.  The u planes are
             //      needed until the last k-quad is built: the next tile's loads go out behind the MFMAs of the last but one.
-            static_assert(MODE == 0 && ND == 3 && M == 1 && !ALDS && !W8 && !kPrep && (kDbg & ~128) == 0, "interleaved B build: plain div of tetrahedra");
+            static_assert(MODE == 0 && ND == 3 && M == 1 && !ALDS && !W8 && !kPrep && !(x_no_mfma || x_no_stores || x_reg_prefetch || x_no_loads || x_early_request || x_one_plane || x_lds_ticket), "interleaved B build: plain div of tetrahedra");
             double jac[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) jac[k] = L->j[k * G::TEL + n];
@@ -971,11 +982,11 @@ __device__ __forceinline__ void div3d_mfma_body(
                     resolve_next_tile(tile, fk, next_new_tile, nt);
                     if (nt < tEnd) issue_loads(nt, nk, next_new_tile);
                     else if (!kDyn && q_e0 >= 0) issue_quarter_loads();   // behind this wave's last full tile: its quarter tile
-                    FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the last B fragments built, the next unit's loads issued
+                    FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the last B fragments built, the next unit's loads issued
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
+            FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
             double* ob = L->o;
 #pragma unroll
             for (int t = 0; t < G::BT; ++t)
@@ -997,7 +1008,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                 }
             }
             wave_lds_fence();
-            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
+            FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
             ++dbg_it;
             fk = nk;
             tile = nt;
@@ -1054,9 +1065,9 @@ __device__ __forceinline__ void div3d_mfma_body(
                 for (int k = 0; k < ND * ND; ++k) asm volatile("" : "+v"(jkeep[m][k]));
         }
         resolve_next_tile(tile, fk, next_new_tile, nt);   // (dynamic walk: the ticket asked for earlier is read here)
-        if (nt < tEnd && !(kDbg & 8)) issue_loads(nt, nk, next_new_tile);
-        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // B fragments built, the next unit's loads issued
-        if constexpr ((kDbg & 64) != 0 && MODE == 0 && ND == 3 && M == 1) {
+        if (nt < tEnd && !x_no_loads) issue_loads(nt, nk, next_new_tile);
+        FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // B fragments built, the next unit's loads issued
+        if constexpr (x_lds_ticket && MODE == 0 && ND == 3 && M == 1) {
             // experiment (kDbg & 64): touch the tile AFTER next -- one dword per 128-byte line of its three planes and nine J rows --
             // so that its LDS-DMA loads, which can only go out one MFMA phase ahead of their use, find the lines in the L2
             const int64_t pt = nt + stride;
@@ -1145,7 +1156,7 @@ __device__ __forceinline__ void div3d_mfma_body(
             for (int t = 0; t < G::BT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < G::NS; ++q) accs[q] = 0.0;
-            if (kDbg & 1) {
+            if (x_no_mfma) {
                 double sum = 0.0;
 #pragma unroll
                 for (int jq = 0; jq < G::KSJ; ++jq)
@@ -1170,7 +1181,7 @@ __device__ __forceinline__ void div3d_mfma_body(
                     }
             }
 
-            FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
+            FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the matrix work is issued
             // ---- transposed store.  16x16x4 C/D: lane (g, n) holds out[e][16t + g + 4q'];
             //      4x4x4_4b D of group q: lane (g, n) holds out[e][16 BT + 4q + g]
             double* ob = L->o;
@@ -1190,13 +1201,13 @@ __device__ __forceinline__ void div3d_mfma_body(
                 const int qc = c * 64 + lane;
                 if ((c + 1) * 64 <= G::SUB_CHUNKS || qc < G::SUB_CHUNKS) {
                     const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * tile_dst_chunk<NP>(qc));
-                    if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * qc] = val[1]; }
+                    if (x_no_stores) { if (val[0] == 1.2345e-300) op[2 * qc] = val[1]; }
                     else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * qc));
                 }
             }
             wave_lds_fence();
         }
-        FE_TILE_STAMP(kDbg & 128, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
+        FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 3);   // the stores are issued
         ++dbg_it;
         fk = nk;
         tile = nt;

@@ -256,7 +256,18 @@ __device__ __forceinline__ void grad3d_mfma_body(
     WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;
     typename G::WaveOut* LO = reinterpret_cast<typename G::WaveOut*>(smem + G::IN_BYTES) + wave;
     const int n = lane & 15, g = lane >> 4;
-    constexpr bool kNT = (kDbg & 16) == 0;
+    // Experiment switches (the `kDbg` template constant): they exist in the experiments build only (tools/build_experiments.sh);
+    // in the product every one of them is the constant `false`.
+#ifdef FE_EXPERIMENTS
+    constexpr bool x_no_mfma = (kDbg & 1) != 0, x_no_stores = (kDbg & 2) != 0, x_plain_stores = (kDbg & 4) != 0, x_no_loads = (kDbg & 8) != 0,
+                   x_plain_loads = (kDbg & 16) != 0, x_stamps = (kDbg & 32) != 0, x_no_balance = (kDbg & 64) != 0, x_split_walk = (kDbg & 128) != 0;
+#else
+    static_assert(kDbg == 0, "experiment flags: experiments build only");
+    constexpr bool x_no_mfma = false, x_no_stores = false, x_plain_stores = false, x_no_loads = false, x_plain_loads = false, x_stamps = false,
+                   x_no_balance = false, x_split_walk = false;
+#endif
+    (void)x_stamps;
+    constexpr bool kNT = !x_plain_loads;
 
     const int64_t stride = (int64_t)nblk * G::WAVES;
     int64_t tile = (int64_t)bid * G::WAVES + wave;
@@ -285,17 +296,17 @@ __device__ __forceinline__ void grad3d_mfma_body(
 
     double afrag[G::RT][G::KS];
     // (one sub-tile per wave tile) stage 1 of the wave's first unit runs with the fragment build: see the prologue
-    constexpr bool kFusedFirst = (M == 1) && !kPrep && !kDyn && (kDbg & ~32) == 0;   // (the dynamic-walk kernels have no registers to spare for it)
+    constexpr bool kFusedFirst = (M == 1) && !kPrep && !kDyn && !(x_no_mfma || x_no_stores || x_plain_stores || x_no_loads || x_plain_loads || x_no_balance || x_split_walk);   // (the dynamic-walk kernels have no registers to spare for it)
     v4d acc_first[G::RT];
     bool first_ready = false;
     // experiment (kDbg & 128): the walk covers both halves of the element range at once (see fe_div.h, kDbg & 4)
     const int64_t half_tiles = (nTiles + 1) / 2;
-    auto phys = [&](int64_t t) -> int64_t { return (kDbg & 128) ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
+    auto phys = [&](int64_t t) -> int64_t { return x_split_walk ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
     const bool dyn = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
     bool pre = false;   // unit 1 already requested
     // the loads of this wave's first two units (behind the operator copy / the fragment loads)
     auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
-        if (!(tile < tEnd) || (kDbg & 8)) return 0;
+        if (!(tile < tEnd) || x_no_loads) return 0;
         grad_issue_u<NP, M, kNT>(P.u[0], phys(tile), lane, lds_addr_uniform(L->u[0]), tload);
         grad_issue_j<NP, M, kPlain>(P, E, phys(tile), lane, lds_addr_uniform(L->j[0]));
         if (nb > 1) {
@@ -336,7 +347,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // one (tile, field) unit: stage 1, stage 2 and the transposed stores, from the u tile `ut` and the J tile `jt` in LDS
     auto compute_unit = [&](int64_t tile_, int fk, const double* ut, const double* jt, auto with_acc) {
         constexpr bool kHaveAcc = decltype(with_acc)::value;   // stage 1 of this unit is in acc_first already
-        FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
+        FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 0);   // this unit's loads have landed
         double* out_x[3];
         out_x[0] = grad_plane_out(P, fk, 0);
         out_x[1] = kPlain ? out_x[0] + E * NP : grad_plane_out(P, fk, 1);
@@ -360,7 +371,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
 #pragma unroll
                 for (int t = 0; t < G::RT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-                if (kDbg & 1) {
+                if (x_no_mfma) {
 #pragma unroll
                     for (int t = 0; t < G::RT; ++t)
                         acc[t] = v4d{bfrag[t % G::KS], bfrag[(t + 1) % G::KS], bfrag[(t + 2) % G::KS], afrag[t][0]};
@@ -373,7 +384,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
             }
 
-            FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the matrix work is issued
+            FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 1);   // the matrix work is issued
             // ---- stage 2 + transposed store, plane by plane
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
@@ -395,7 +406,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
                 wave_lds_fence();
                 double* op = out_x[x] + (e0 + 16 * m) * NP;
-                if constexpr (kPlain && (kDbg & ~32) == 0) {
+                if constexpr (kPlain && !(x_no_mfma || x_no_stores || x_plain_stores || x_no_loads || x_plain_loads || x_no_balance || x_split_walk)) {
                     if (wthrough) {   // all values out of LDS first, then the stores back to back (as the compiler orders its own)
                         v2d vals[G::SUB_INSTR];
 #pragma unroll
@@ -413,15 +424,15 @@ __device__ __forceinline__ void grad3d_mfma_body(
                     const int q = c * 64 + lane;
                     if ((c + 1) * 64 <= G::SUB_CHUNKS || q < G::SUB_CHUNKS) {
                         const v2d val = *reinterpret_cast<const v2d*>(ob + 2 * q);
-                        if (kDbg & 2) { if (val[0] == 1.2345e-300) op[2 * q] = val[1]; }   // keep the value live
-                        else if (kDbg & 4) *reinterpret_cast<v2d*>(op + 2 * q) = val;
+                        if (x_no_stores) { if (val[0] == 1.2345e-300) op[2 * q] = val[1]; }   // keep the value live
+                        else if (x_plain_stores) *reinterpret_cast<v2d*>(op + 2 * q) = val;
                         else __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(op + 2 * q));
                     }
                 }
                 wave_lds_fence();
             }
         }
-        FE_TILE_STAMP(kDbg & 32, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the stores are issued
+        FE_TILE_STAMP(x_stamps, smem + G::LDS_BYTES, wave, lane, dbg_it, 2);   // the stores are issued
         ++dbg_it;
     };
 
@@ -458,7 +469,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     // ---- the walk.  A step has a TOP (the next unit's loads and, under the dynamic walk, the ticket traffic go out; wait for this
     //      unit's loads) and a BOTTOM (stage 1, stage 2, the transposed stores; advance).  The top of a wave's first step runs in the
     //      prologue, in front of the fragment build that is fused with that unit's stage 1 (kFusedFirst).
-    const bool younger_half = !(kDbg & 64) && bid >= (nblk + 1) / 2;
+    const bool younger_half = !x_no_balance && bid >= (nblk + 1) / 2;
     int iteration = 0;
     // (a) dynamic walk of one field (fe_common.h): static tiles first + k stride below t_static, then tickets.
     //     Vector-memory ops of an iteration in issue order: [A = ticket for the tile after next] L(next) S(cur);
@@ -565,19 +576,19 @@ __device__ __forceinline__ void grad3d_mfma_body(
                 }
             }
         }
-        if (kDbg & 8) {
+        if (x_no_loads) {
             wait_vmcnt<0>();
         } else if (nt < tEnd) {
             if (!pre) grad_issue_u<NP, M, kNT>(grad_field_u(P, nk), phys(nt), lane, lds_addr_uniform(L->u[ub ^ 1]), tload);
             if (next_new_tile) {
                 if (!pre) grad_issue_j<NP, M, kPlain>(P, E, phys(nt), lane, lds_addr_uniform(L->j[jbuf ^ 1]));
-                if ((kDbg & 2) || first) wait_vmcnt<G::LOADS>();
+                if (x_no_stores || first) wait_vmcnt<G::LOADS>();
                 else wait_vmcnt_planes<G::LOADS, G::PLANE_STORES>(nx);
             } else if (kDyn && extra) {
                 if (first) wait_vmcnt<G::U_INSTR + 1>();
                 else wait_vmcnt<G::U_INSTR + G::STORES + 1>();
             } else {
-                if ((kDbg & 2) || first) wait_vmcnt<G::U_INSTR>();
+                if (x_no_stores || first) wait_vmcnt<G::U_INSTR>();
                 else wait_vmcnt_planes<G::U_INSTR, G::PLANE_STORES>(nx);
             }
         } else if (q_e0 >= 0) {   // (static walk, one field) the last full tile: behind its loads go the quarter tile's
@@ -586,7 +597,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
             else wait_vmcnt<kQuarterLoads + G::STORES>();
         } else {
             if (kDyn && extra) wait_vmcnt<G::STORES + 1>();
-            else if (first || (kDbg & 2)) wait_vmcnt<0>();
+            else if (first || x_no_stores) wait_vmcnt<0>();
             else wait_vmcnt_planes<0, G::PLANE_STORES>(nx);
         }
         first = false;
