@@ -357,9 +357,15 @@ std::atomic<long long> g_temporal_input_bytes{[] {
     const char* e = getenv("FEINSUM_TEMPORAL_LOADS_MIB");
     return e ? (long long)atoll(e) << 20 : fe::kTemporalInputBytes;
 }()};
-int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0) {
-    const long long cap = g_temporal_input_bytes.load(std::memory_order_relaxed);
+// `wide`: launches with face-mass in them (face-mass alone, the wave operator) gain from plain loads up to inputs of 320 MiB --
+// more than the cache holds, but what it holds of them is found again -- and lose beyond (profiles/r05/temporal_loads_fused_ab.txt:
+// the pipeline at E = 1e5, inputs 307 MiB, 99.6 -> 94.8 us; face-mass x 4 at 1.5e5, 279 MiB, 80.7 -> 72.3; level at 325 - 331 MiB,
+// +2 ... 4 % at 335 - 370); grad, div and div + grad lose from 250 - 260 MiB on.  The caller's setting scales with it (0 = never).
+constexpr long long kTemporalWideNum = 320, kTemporalWideDen = 248;
+int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0, bool wide = false) {
+    long long cap = g_temporal_input_bytes.load(std::memory_order_relaxed);
     if (cap >= (1ll << 40)) return fe::kOpLoadsTemporal;        // "always" (A/B runs)
+    if (wide) cap = cap / kTemporalWideDen * kTemporalWideNum;
     return input_bytes <= cap && input_bytes >= min_bytes ? fe::kOpLoadsTemporal : 0;
 }
 constexpr int64_t kTemporalFloorDiv = 80ll << 20, kTemporalFloorFaceMass = 64ll << 20;
@@ -931,7 +937,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
     constexpr bool kCanPrep = !ALDS && NF == fe::kFmNf;   // prepared operators: tetrahedra p = 1..4
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
-    jfe = (jfe ? 1 : 0) | temporal_flag((NF + (int64_t)NB * NF * NFP) * E * 8, kTemporalFloorFaceMass);
+    jfe = (jfe ? 1 : 0) | temporal_flag((NF + (int64_t)NB * NF * NFP) * E * 8, kTemporalFloorFaceMass, true);
     static PerDeviceOnce once_plain, once_prepared;
     char what[96];
     int attr_rc = FE_OK;
@@ -1164,7 +1170,7 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
         if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
     }
     fe::WaveOpArgs args = a;
-    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8);
+    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8, 0, true);
     if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);
