@@ -94,9 +94,11 @@ def rank_elements(args, info) -> int:
     return args.elems_per_gpu
 
 
-def timed_region(step_batch, steps: int, sync, device=None):
+def timed_region(step_batch, steps: int, sync, device=None, keep_busy=None):
     """barrier + sync | K steps | sync | barrier + sync.  *step_batch(n)* enqueues n steps and returns their device
-    seconds.  Returns a dict of seconds:
+    seconds.  *keep_busy()* (a few untimed launches + synchronize) is what a rank does while it waits in the OPENING barrier for
+    the others, so that no rank times its steps on a device that has just been idling (parallel.barrier_keeping_busy).
+    Returns a dict of seconds:
 
     ``wall``            MAX over ranks of each rank's own [after the opening barrier, its own K steps done and synchronised]
                         -- the sharded path has no data-path collective, so this is when the job's work is done;
@@ -109,7 +111,7 @@ def timed_region(step_batch, steps: int, sync, device=None):
     from feinsum_amd import parallel
 
     sync()
-    parallel.barrier()
+    busy_calls = parallel.barrier_keeping_busy(keep_busy)
     sync()
     t0 = time.perf_counter()
     kernel_s = step_batch(steps)
@@ -119,7 +121,8 @@ def timed_region(step_batch, steps: int, sync, device=None):
     sync()
     closed_s = time.perf_counter() - t0
     return {"wall": parallel.max_over_ranks(local_s, device), "wall_barrier": parallel.max_over_ranks(closed_s, device),
-            "kernel": parallel.max_over_ranks(kernel_s, device), "local_wall": local_s, "local_kernel": kernel_s}
+            "kernel": parallel.max_over_ranks(kernel_s, device), "local_wall": local_s, "local_kernel": kernel_s,
+            "opening_barrier_busy_calls": busy_calls}
 
 
 _PLACEMENT_MODES = ("split", "separate", "separate (split allocator failed)")
@@ -134,12 +137,15 @@ def gather_rank_reports(report: dict, device=None) -> list:
 
     mode = report.get("placement_mode", "separate")
     row = [report["elements"], report["kernel_ms"], report["wall_ms"], _PLACEMENT_MODES.index(mode) if mode in _PLACEMENT_MODES else 1,
-           report.get("unsplit_arrays", 0), report.get("allocator_ms", 0.0), report.get("search_ms", 0.0), report.get("release_ms", 0.0)]
+           report.get("unsplit_arrays", 0), report.get("allocator_ms", 0.0), report.get("search_ms", 0.0), report.get("release_ms", 0.0),
+           report.get("busy_calls", 0)]
     out = []
     for rank, r in enumerate(parallel.gather_rows(row, device)):
         out.append({"rank": rank, "elements": int(r[0]), "kernel_ms": round(r[1], 5), "wall_ms": round(r[2], 5),
                     "placement_mode": _PLACEMENT_MODES[int(r[3])], "unsplit_arrays": int(r[4]), "allocator_ms": round(r[5], 1),
-                    "allocator_search_ms": round(r[6], 1), "allocator_release_ms": round(r[7], 1)})
+                    "allocator_search_ms": round(r[6], 1), "allocator_release_ms": round(r[7], 1),
+                    # (how long this rank kept its device busy in the opening barrier while the others arrived: calls of ~1 ms)
+                    "opening_barrier_busy_calls": int(r[8]) if len(r) > 8 else 0})
     return out
 
 
@@ -613,6 +619,8 @@ def main() -> None:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = torch.device("cuda", info.local_rank)
     torch.cuda.set_device(device)
+    # the first collective creates the communicator (RCCL: hundreds of milliseconds): here, not in front of the timed region
+    parallel.barrier()
     q = f.DeviceQueue(device)
     E = rank_elements(args, info)
     sync = lambda: torch.cuda.synchronize(device)   # noqa: E731
@@ -717,7 +725,12 @@ def main() -> None:
 
     step_batch = step_batch_of(op)
 
-    timed = timed_region(step_batch, args.steps, sync, device)
+    def keep_busy():     # (a rank waiting in the opening barrier: ~1 ms of the same launches, untimed)
+        for _ in range(max(1, min(50, int(1e-3 / max(setup_seconds / max(setup_launches, 1), 1e-6))))):
+            op.launch(s)
+        torch.cuda.current_stream(device).synchronize()     # (the launch stream only: the barrier's own kernel is still waiting on its stream)
+
+    timed = timed_region(step_batch, args.steps, sync, device, keep_busy)
     wall_s, kernel_s = timed["wall"], timed["kernel"]
     launch_info = _hip.last_launch_info()      # what the launcher decided for the timed launches (fe_last_launch_info)
     pool_r = placement_report.get("pool") or {}
@@ -725,7 +738,8 @@ def main() -> None:
                                     "placement_mode": ("split" if placement_report.get("mode") == "split" else
                                                        "separate (split allocator failed)" if "fallback" in placement_report else "separate"),
                                     "unsplit_arrays": (pool_r.get("unsplit_arrays", 0) or 0) + (pool_r.get("unsplit_refused", 0) or 0), "allocator_ms": placement_report.get("allocator_ms", 0.0),
-                                    "search_ms": pool_r.get("search_ms", 0.0) or 0.0, "release_ms": pool_r.get("release_ms", 0.0) or 0.0}, device)
+                                    "search_ms": pool_r.get("search_ms", 0.0) or 0.0, "release_ms": pool_r.get("release_ms", 0.0) or 0.0,
+                                    "busy_calls": timed.get("opening_barrier_busy_calls", 0)}, device)
 
     # the reference's own protocol on the same bound launch (every rank, no barrier inside)
     protocol_ms = None

@@ -255,6 +255,37 @@ def barrier() -> None:
             dist.barrier()
 
 
+def barrier_keeping_busy(keep_busy: Any = None) -> int:
+    """
+    A barrier that does not let this rank's GPU fall idle while it waits for the others.  An MI355X that has had nothing to do
+    for more than about two milliseconds lowers its clocks, and the next milliseconds of work run 10-20 % slower (grad at E = 1e6:
+    20 launches after 5 ms of idling 209 us each, after 20 ms 225, against 188: ``tools/idle_gap_probe.py``) -- ranks reach a barrier
+    at different times (allocator searches of 0.1 ... 4 s), so a plain barrier in front of a short timed region would have most
+    ranks time their steps on a device that has just been waiting.  Here the barrier is asynchronous and *keep_busy()* -- a few
+    launches of the workload followed by a synchronize, about a millisecond -- is called until every rank has arrived.  Returns the
+    number of calls.  World size 1 / no group: nothing to wait for.
+    """
+    import torch.distributed as dist
+
+    if not in_group():
+        return 0
+    if keep_busy is None:
+        barrier()
+        return 0
+    if dist.get_backend() == "nccl":
+        import torch
+
+        work = dist.barrier(async_op=True, device_ids=[torch.cuda.current_device()])
+    else:
+        work = dist.barrier(async_op=True)
+    calls = 0
+    while not work.is_completed():
+        keep_busy()
+        calls += 1
+    work.wait()
+    return calls
+
+
 def gather_rows(values: Sequence[float], device: Any = None) -> List[List[float]]:
     """Every rank's row of floats (equal lengths), in rank order; one all-gather of a small float64 tensor."""
     import torch

@@ -49,13 +49,20 @@ def _worker(rank, world, port, elems_total, elems_per_gpu, tmpdir):
         time.sleep(0.02 * (rank + 1) * n)
         return 0.01 * (rank + 1) * n
 
-    timed = bench.timed_region(step_batch, 3, sync=lambda: None)
+    # rank 1 reaches the opening barrier 0.3 s late: rank 0 keeps "its device busy" meanwhile (parallel.barrier_keeping_busy)
+    calls = []
+    if rank == 1:
+        time.sleep(0.3)
+    timed = bench.timed_region(step_batch, 3, sync=lambda: None, keep_busy=lambda: (calls.append(1), time.sleep(0.002)))
+    assert timed["opening_barrier_busy_calls"] == len(calls)
+    assert (len(calls) >= 30) if rank == 0 else (len(calls) <= 20), (rank, len(calls))
     wall_s, kernel_s = timed["wall"], timed["kernel"]
     # the closing barrier is outside `wall`: rank 0 is done after 3 x 20 ms and only then waits for rank 1
     assert timed["local_wall"] == pytest.approx(0.06 * (rank + 1), abs=0.03) and timed["local_kernel"] == pytest.approx(0.03 * (rank + 1))
     assert timed["wall_barrier"] >= timed["wall"] >= timed["local_wall"]
     per_rank = bench.gather_rank_reports({"elements": E, "kernel_ms": timed["local_kernel"] / 3 * 1e3, "wall_ms": timed["local_wall"] / 3 * 1e3,
-                                          "placement_mode": "split", "unsplit_arrays": rank, "allocator_ms": 10.0 * rank})
+                                          "placement_mode": "split", "unsplit_arrays": rank, "allocator_ms": 10.0 * rank,
+                                          "busy_calls": timed["opening_barrier_busy_calls"]})
     total, red_ms, gather_ms = bench.exchange_results([torch.from_numpy(out)], sync=lambda: None)
     flops = float(f.count_ops(expr, long_dim_length=E))
     t = torch.tensor([flops], dtype=torch.float64)
@@ -114,6 +121,7 @@ def test_two_rank_bench_logic(tmp_path, elems_total, elems_per_gpu):
     # every rank's own figures reach rank 0: a slow rank (or one whose allocator search failed) is attributable
     pr = rec["per_rank"]
     assert [r["rank"] for r in pr] == [0, 1] and [r["unsplit_arrays"] for r in pr] == [0, 1]
+    assert pr[0]["opening_barrier_busy_calls"] >= 30 and pr[1]["opening_barrier_busy_calls"] <= 20      # rank 0 waited for rank 1, busy
     assert pr[1]["kernel_ms"] == pytest.approx(20.0) and pr[0]["kernel_ms"] == pytest.approx(10.0)
     assert pr[1]["wall_ms"] > pr[0]["wall_ms"] and pr[0]["placement_mode"] == "split"
 
