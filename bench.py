@@ -795,7 +795,7 @@ def main() -> None:
     in_bytes = sum(int(t.numel()) * t.element_size() for t in {id(t): t for _, d in stages for t in d.values()}.values())
     mib_setting = _hip.set_temporal_loads_mib(0)
     plain = bool(launch_info.get("temporal_loads"))       # (the launcher's own decision, not a re-derivation of its rule)
-    loads_report = {"threshold_mib": mib_setting, "threshold_note": "x 320/248 for launches with face-mass in them (fe_set_temporal_loads_mib)",
+    loads_report = {"threshold_mib": mib_setting, "threshold_note": "grad; x 280/248 div, x 310/248 div + grad, x 320/248 launches with face-mass in them (fe_set_temporal_loads_mib)",
                     "launch_input_mib": round(in_bytes / 2**20, 1),
                     "streamed_operand": "plain loads (what the 256 MiB Infinity Cache holds of the launch's inputs a repeated launch finds there)"
                     if plain else "non-temporal loads"}

@@ -357,15 +357,18 @@ std::atomic<long long> g_temporal_input_bytes{[] {
     const char* e = getenv("FEINSUM_TEMPORAL_LOADS_MIB");
     return e ? (long long)atoll(e) << 20 : fe::kTemporalInputBytes;
 }()};
-// `wide`: launches with face-mass in them (face-mass alone, the wave operator) gain from plain loads up to inputs of 320 MiB --
-// more than the cache holds, but what it holds of them is found again -- and lose beyond (profiles/r05/temporal_loads_fused_ab.txt:
-// the pipeline at E = 1e5, inputs 307 MiB, 99.6 -> 94.8 us; face-mass x 4 at 1.5e5, 279 MiB, 80.7 -> 72.3; level at 325 - 331 MiB,
-// +2 ... 4 % at 335 - 370); grad, div and div + grad lose from 250 - 260 MiB on.  The caller's setting scales with it (0 = never).
-constexpr long long kTemporalWideNum = 320, kTemporalWideDen = 248;
-int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0, bool wide = false) {
+// `cap_mib`: up to which size of its inputs a family's launches gain from plain loads -- more than the cache holds for the
+// families whose footprint is mostly inputs: what the cache holds of them is found again.  Measured (profiles/r05/
+// temporal_loads_fused_ab.txt, back-to-back launches on the same arrays): grad gains up to 235 - 245 MiB and loses 1.5 ... 12 % from
+// 245 - 270 on (kTemporalInputBytes = 248 MiB); div gains up to 270 MiB (-4 %), is level at 287 and loses 6 % at 304; div + grad gains
+// up to 301 MiB (-2 %; 253 MiB: -8 %) and loses at 326; launches with face-mass in them -- face-mass alone, the wave operator --
+// gain up to 316 - 325 MiB (the pipeline at E = 1e5, 307 MiB: 99.6 -> 94.8 us; face-mass x 4 at 1.5e5, 279 MiB: 80.7 -> 72.3) and lose
+// 2 ... 4 % at 335 - 370.  The caller's setting (fe_set_temporal_loads_mib; 0 = never) scales every family's cap alike.
+constexpr long long kTemporalCapGradMib = 248, kTemporalCapDivMib = 280, kTemporalCapGradDivMib = 310, kTemporalCapFaceMassMib = 320;
+int temporal_flag(int64_t input_bytes, int64_t min_bytes = 0, long long cap_mib = kTemporalCapGradMib) {
     long long cap = g_temporal_input_bytes.load(std::memory_order_relaxed);
     if (cap >= (1ll << 40)) return fe::kOpLoadsTemporal;        // "always" (A/B runs)
-    if (wide) cap = cap / kTemporalWideDen * kTemporalWideNum;
+    cap = cap / kTemporalCapGradMib * cap_mib;
     return input_bytes <= cap && input_bytes >= min_bytes ? fe::kOpLoadsTemporal : 0;
 }
 constexpr int64_t kTemporalFloorDiv = 80ll << 20, kTemporalFloorFaceMass = 64ll << 20;
@@ -765,7 +768,7 @@ int launch_div(const double* J, const double* D, const void* prep, const fe::Fie
     const int64_t nTiles = E / G::TEL;
     *e_done = nTiles > 0 ? E : 0;   // the launch covers the elements behind the last tile too (remainder_items)
     if (nTiles == 0) return FE_OK;
-    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv);
+    opT |= temporal_flag((9 + 3 * (int64_t)nb * NP) * E * 8, kTemporalFloorDiv, kTemporalCapDivMib);
     static PerDeviceOnce once_plain, once_prepared;
     char what[64];
     int attr_rc;
@@ -937,7 +940,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     constexpr bool W8 = ALDS;   // fragments in LDS: eight waves per block share them, one block per CU
     constexpr bool kCanPrep = !ALDS && NF == fe::kFmNf;   // prepared operators: tetrahedra p = 1..4
     using G = fe::FmGeom<NP, NFP, M, NF, ALDS, W8>;
-    jfe = (jfe ? 1 : 0) | temporal_flag((NF + (int64_t)NB * NF * NFP) * E * 8, kTemporalFloorFaceMass, true);
+    jfe = (jfe ? 1 : 0) | temporal_flag((NF + (int64_t)NB * NF * NFP) * E * 8, kTemporalFloorFaceMass, kTemporalCapFaceMassMib);
     static PerDeviceOnce once_plain, once_prepared;
     char what[96];
     int attr_rc = FE_OK;
@@ -1128,7 +1131,7 @@ int launch_graddiv(const double* J, const double* D, const void* prep, const fe:
     }
     // body order (fe_fused.h): with the static walk the younger half of the grid runs grad first; with tickets every block
     // runs div, then grad (profiles/r03/dynamic_walk_fused.txt: 77.9 - 78.1 against 76.9 - 77.6 %)
-    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8);
+    int op_arg = ((ft.tail ? 0 : kFusedOrderGradDiv) << 8) | temporal_flag((9 + 4 * (int64_t)NP) * E * 8, 0, kTemporalCapGradDivMib);
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) op_arg = atoi(o) << 8;
 #endif
@@ -1170,7 +1173,7 @@ int launch_waveop_nb(const fe::WaveOpArgs& a, const fe::GradFields& Pg, const fe
         if (ft.static_d < a.nTilesD || ft.static_g < a.nTilesG || ft.static_f < a.nTilesF) ft.tail = tail_slot(s, 3);
     }
     fe::WaveOpArgs args = a;
-    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8, 0, true);
+    args.load_flags = temporal_flag((9 + 4 * (int64_t)NP + 4 + (int64_t)NB * 4 * NFP) * a.E * 8, 0, kTemporalCapFaceMassMib);
     if (ft.tail) args.order = 0;   // with tickets every block runs div, grad, lift (see launch_graddiv)
 #ifdef FE_EXPERIMENTS
     if (const char* o = getenv("FE_FUSED_ORDER")) args.order = atoi(o);

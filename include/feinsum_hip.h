@@ -438,9 +438,9 @@ int fe_tail_plant(void* stream, uint32_t value);
  * are at most `mib` MiB (default 248, also FEINSUM_TEMPORAL_LOADS_MIB; 0 = never): then they are plain loads that may stay in
  * the 256 MiB Infinity Cache, where the next launch on the same arrays finds them (grad at the reference's default E = 1e5,
  * src/feinsum/measure.py:202: 24.8 -> 23.1 us; above the cache size plain loads cost 7-12 %; div and face-mass launches
- * switch only above 80 / 64 MiB of inputs, below which plain loads measured slower; launches with face-mass in them -- face-mass
- * alone, the wave operator -- keep plain loads up to 320/248 of `mib`, where they still gain: the pipeline at E = 1e5, inputs
- * 307 MiB, 99.6 -> 94.8 us; 1048576 or more = always, for A/B runs).  Stores are non-temporal at every
+ * switch only above 80 / 64 MiB of inputs, below which plain loads measured slower; the families whose footprint is mostly inputs
+ * keep plain loads beyond `mib`, where they still gain -- div up to 280/248 of it, div + grad 310/248, launches with face-mass in
+ * them 320/248: the pipeline at E = 1e5, inputs 307 MiB, 99.6 -> 94.8 us; 1048576 or more = always, for A/B runs).  Stores are non-temporal at every
  * size.  Applies to the MFMA kernels of the orders p = 1..4 (float64).  Returns the previous setting.  Results do not depend
  * on it. */
 int fe_set_temporal_loads_mib(int32_t mib);
