@@ -102,7 +102,8 @@ constexpr long long kTemporalInputBytes = 248ll << 20;
 // Measured on grad (profiles/r04/store_policies_small_sizes.txt): E = 1e5 24.0 -> 23.3 us, 2e5 41.1 -> 40.6; at 5e5 write-through
 // without nt costs 16 % and with nt it is level -- the write-back at the end is a fixed cost that only short launches see.
 constexpr int kOpStoresWriteThrough = 32;
-constexpr long long kWriteThroughOutputBytes = 128ll << 20;
+constexpr long long kWriteThroughOutputBytes = 176ll << 20;   // (round 5, with write-through under the dynamic walk too: -2 ... -3 % at outputs of
+                                                               //  128 - 160 MiB, +1 % at 200, +9 ... 12 % from 240 on: profiles/r05/write_through_threshold_ab.txt)
 // kOpPhasePriority (round 5; the eight-wave p = 5 kernels, opt-in: fe_set_phase_priority_p5): a wave's f64 VALU phases -- the
 // B-fragment build of div, the Jacobian contraction of grad -- at raised issue priority, its matrix phases at priority 0.
 // Measured: p = 5 div -1.0 ... -1.3 % at E >= 1e6, grad -0.8 ... +1.5 % (profiles/r05/p5_phase_priorities_ab.txt).  On the p = 4

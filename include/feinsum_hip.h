@@ -446,7 +446,7 @@ int fe_tail_plant(void* stream, uint32_t value);
 int fe_set_temporal_loads_mib(int32_t mib);
 
 /* Output stores are non-temporal -- except in grad launches (p = 1..4, one field, static walk) that write at most `mib` MiB
- * (default 128, also FEINSUM_WRITE_THROUGH_MIB; 0 = never): those store write-through (sc0 sc1), which leaves no dirty lines for
+ * (default 176, also FEINSUM_WRITE_THROUGH_MIB; 0 = never): those store write-through (sc0 sc1), which leaves no dirty lines for
  * the end of the launch to write back (E = 1e5: 24.0 -> 23.3 us).  Returns the previous setting.  Results do not depend on it. */
 int fe_set_write_through_mib(int32_t mib);
 
