@@ -332,13 +332,18 @@ std::atomic<int> g_tail_min_rounds_v{[] { const char* e = getenv("FEINSUM_TAIL_M
 // follow each other, so a block that is late in one body starts the next late, and tickets absorb that: div + grad at E = 1e5
 // 46.1 -> 43.4 us, the pipeline 103.9 -> 97.5, -1 ... -6 % at every size between three and four and a half rounds, level at exact
 // multiples (profiles/r05/fused_tickets3_ab.txt); single launches lose up to 8 % there (single_tickets3_ab.txt) and keep four.
-int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock, bool fused = false) {
+// `units`: a face-mass launch of four fields (p = 4) walks four units per tile, so a ticket's round trip hides behind more work: it
+// gains from tickets from three rounds on as the fused launches do -- E = 1e5 52.3 -> 51.0 us, 1.2e5 -3.6 %, 1.4e5 -2.3 %, level
+// at 1.1e5 -- except where the tiles fill whole rounds, which are balanced as they are (98 304: +3.6 % with tickets;
+// profiles/r05/facemass_tickets_from_three_rounds_ab.txt).
+int64_t tail_static_tiles(int64_t nTiles, int64_t blocks, int wavesPerBlock, bool fused = false, bool units = false) {
     const int dyn_rounds = g_tail_rounds.load(std::memory_order_relaxed);
     const int64_t waves = blocks * wavesPerBlock;
     const int64_t rounds = waves > 0 ? nTiles / waves : 0;
-    const int min_rounds = (fused && g_tail_min_rounds == 4) ? 3 : g_tail_min_rounds;
+    const int min_rounds = ((fused || units) && g_tail_min_rounds == 4) ? 3 : g_tail_min_rounds;
     if (blocks < 8 * fe::kTailPools) return nTiles;
     if (dyn_rounds < 0 || rounds < min_rounds || nTiles >= ((int64_t)1 << 29)) return nTiles;   // (32-bit ticket arithmetic: fe_common.h)
+    if (units && !fused && rounds <= 4 && nTiles == rounds * waves) return nTiles;
     // four rounds and a bit: tickets pay once the partial fifth round is at least half a round -- a static walk leaves those waves
     // a tile behind the rest (div E = 163 000: 41.2 -> 37.7 us; grad 150 000: 34.4 -> 33.5), while four EXACT rounds are perfectly
     // balanced as they are (grad 131 072: 28.6 static, 30.7 with tickets; profiles/r04/dynamic_walk_from_four_and_a_half_rounds.txt)
@@ -983,7 +988,7 @@ int launch_fm_nb(const double* J, const double* R, const void* prep, const fe::F
     }
     if constexpr (!ALDS && NB >= 3) {   // tetrahedra p = 1 .. 4 and triangles, three or more fields
         // behind two static rounds the tiles come by tickets (fe_common.h, dynamic walk)
-        const int64_t t_static = tail_static_tiles(nTiles, blocks, G::WAVES);
+        const int64_t t_static = tail_static_tiles(nTiles, blocks, G::WAVES, false, NP == 35 && NF == fe::kFmNf && NB == 4);
         unsigned* tail = t_static < nTiles ? tail_slot(s) : nullptr;
         if (tail) {
             static PerDeviceOnce once_tail;
