@@ -278,8 +278,11 @@ def barrier_keeping_busy(keep_busy: Any = None) -> int:
         work = dist.barrier(async_op=True, device_ids=[torch.cuda.current_device()])
     else:
         work = dist.barrier(async_op=True)
+    import time
+
     calls = 0
-    while not work.is_completed():
+    deadline = time.monotonic() + 120.0     # (a backend whose handle never reports completion must not hang the job: then wait, blocking)
+    while not work.is_completed() and time.monotonic() < deadline:
         keep_busy()
         calls += 1
     work.wait()
