@@ -184,49 +184,6 @@ __device__ __forceinline__ void div3d_mfma_body(
             }
         });
     };
-    if constexpr (!kPrep) {
-        double* dl = reinterpret_cast<double*>(smem);
-        stage_operator<G::OP_D, G::THREADS>(D, dl);
-        __syncthreads();
-        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored [r][j][i]
-#pragma unroll
-        for (int jq = 0; jq < G::KSJ; ++jq) {
-            const int j = 4 * jq + g;
-            const double* col = dl + (j < NP ? j : 0) * jstride + n * istride;
-#pragma unroll
-            for (int r = 0; r < NC; ++r)
-#pragma unroll
-                for (int t = 0; t < G::BT; ++t) {
-                    const double v = col[r * (NP * NP) + 16 * t * istride];
-                    if (ALDS) {
-                        // every wave builds the same fragments: wave w stores those of the k-quads jq = w mod 4
-                        if (jq % G::WAVES == wave) afr[((jq * NC + r) * G::BT + t) * 64 + lane] = (j < NP) ? v : 0.0;
-                    } else {
-                        abig[t][jq][r] = (j < NP) ? v : 0.0;
-                    }
-                }
-        }
-        for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += G::THREADS) {
-            const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
-            const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
-            asmall[idx] = (j < NP && i < NP) ? dl[r * (NP * NP) + i * istride + j * jstride] : 0.0;
-        }
-        // (while the block's copy of the operator is still there; not in the eight-wave p = 5 kernels, whose prologue has no registers
-        //  to spare: the compiler took the ticket registers for it -- tests/test_ticket_registers.py)
-        if constexpr (!ALDS && !W8) remainder(dl);
-        __syncthreads();   // the staging area is reused as the waves' private buffers from here on
-        if constexpr (ALDS || W8) remainder(D);
-    } else {
-        remainder(D);
-    }
-    const double* as_lane = asmall + g * 4 + (n & 3);
-    const double* af_lane = afr + lane;
-    auto a_big = [&](int t, int jq, int r) -> double {
-        if constexpr (ALDS) return af_lane[((jq * NC + r) * G::BT + t) * 64];
-        else return abig[t][jq][r];
-    };
-
-
     const unsigned lds_u = lds_addr_uniform(L->u[0]);
     const unsigned lds_j = lds_addr_uniform(L->j);
     const int64_t stride = (int64_t)nblk * G::WAVES;
@@ -304,6 +261,61 @@ __device__ __forceinline__ void div3d_mfma_body(
         }
     };
     int64_t tile = (int64_t)bid * G::WAVES + wave;
+    // Waves whose own buffers the operator's staging area does not reach (it covers the first OP_D doubles of the block's LDS: waves 0
+    // and 1 at p = 4) request their first tile as soon as the operator's loads are through -- 1 - 2 us before the others can, which
+    // is when the first round's 27 MB start to move (profiles/r05/div_prologue_phases.txt: requested behind the prologue by all waves
+    // at once, they arrive at 4.8 us in the older and 6.5 us in the younger block of a CU).  Behind the OPERATOR's loads, not in
+    // front: vector-memory data return in order per CU, and the other block's operator must not queue behind tile data.
+    bool first_requested = false;
+    if constexpr (!kPrep) {
+        double* dl = reinterpret_cast<double*>(smem);
+        stage_operator<G::OP_D, G::THREADS>(D, dl);
+        __syncthreads();
+        if constexpr (!ALDS && !W8 && !G::STREAM) {   // (behind the barrier: the requests take their waves 0.3 - 1 us to issue, which the block need not wait for)
+            if (wave * (int)sizeof(WaveLds) >= G::OP_D * 8 && tile < tEnd && !x_no_loads) {
+                issue_loads(tile, 0, true);
+                first_requested = true;
+            }
+        }
+        const int istride = opT ? 1 : NP, jstride = opT ? NP : 1;   // opT: D stored [r][j][i]
+#pragma unroll
+        for (int jq = 0; jq < G::KSJ; ++jq) {
+            const int j = 4 * jq + g;
+            const double* col = dl + (j < NP ? j : 0) * jstride + n * istride;
+#pragma unroll
+            for (int r = 0; r < NC; ++r)
+#pragma unroll
+                for (int t = 0; t < G::BT; ++t) {
+                    const double v = col[r * (NP * NP) + 16 * t * istride];
+                    if (ALDS) {
+                        // every wave builds the same fragments: wave w stores those of the k-quads jq = w mod 4
+                        if (jq % G::WAVES == wave) afr[((jq * NC + r) * G::BT + t) * 64 + lane] = (j < NP) ? v : 0.0;
+                    } else {
+                        abig[t][jq][r] = (j < NP) ? v : 0.0;
+                    }
+                }
+        }
+        for (int idx = threadIdx.x; idx < G::ASMALL_D; idx += G::THREADS) {
+            const int row4 = idx & 3, gg = (idx >> 2) & 3, q = (idx >> 4) % G::NS, ks = (idx >> 4) / G::NS;
+            const int i = 16 * G::BT + 4 * q + row4, j = 4 * (ks / NC) + gg, r = ks % NC;
+            asmall[idx] = (j < NP && i < NP) ? dl[r * (NP * NP) + i * istride + j * jstride] : 0.0;
+        }
+        // (while the block's copy of the operator is still there; not in the eight-wave p = 5 kernels, whose prologue has no registers
+        //  to spare: the compiler took the ticket registers for it -- tests/test_ticket_registers.py)
+        if constexpr (!ALDS && !W8) remainder(dl);
+        __syncthreads();   // the staging area is reused as the waves' private buffers from here on
+        if constexpr (ALDS || W8) remainder(D);
+    } else {
+        remainder(D);
+    }
+    const double* as_lane = asmall + g * 4 + (n & 3);
+    const double* af_lane = afr + lane;
+    auto a_big = [&](int t, int jq, int r) -> double {
+        if constexpr (ALDS) return af_lane[((jq * NC + r) * G::BT + t) * 64];
+        else return abig[t][jq][r];
+    };
+
+
     if constexpr (G::STREAM) {
         // ---- plane streaming (see DivGeom): per (tile, field) unit
         //   L(p0), L(J) | L(p1) -> B += plane 0 | L(p2) -> B += plane 1 -> B += plane 2 | L(p0', J') | MFMAs | stores
@@ -822,7 +834,7 @@ __device__ __forceinline__ void div3d_mfma_body(
         }
         __syncthreads();   // the table of the 4-row groups is complete
     } else {
-        if (tile < tEnd && !x_no_loads) issue_loads(tile, 0, true);
+        if (!first_requested && tile < tEnd && !x_no_loads) issue_loads(tile, 0, true);
     }
     // ---- the quarter tile of this wave (see above): loads, and the unit itself
     bool q_issued = false;

@@ -156,6 +156,7 @@ __device__ __forceinline__ void facemass_mfma_body(
             facemass_item<NB>(J, Rsrc, P, E, NP, NF, NFP, jEs, jFs, rF, rI, rJ, e, i);
         });
     };
+    bool first_requested = false;   // (units 0 and 1 of this wave's first tile: see the staged prologue)
     if constexpr (kPrep) {
         load_prepared_fragments<(G::BT + G::NS) * G::KS>(reinterpret_cast<const char*>(prep) + kPrepFmOff, lane,
                                                        [&](int f, double v) {
@@ -167,6 +168,18 @@ __device__ __forceinline__ void facemass_mfma_body(
         double* rl = reinterpret_cast<double*>(smem);
         stage_operator<G::OP_D, G::THREADS>(R, rl);
         __syncthreads();
+        // Waves whose own buffers the staging area does not reach (it covers the first OP_D doubles of the block's LDS: wave 0 at
+        // p = 4) request the first two units of their first tile NOW, behind the operator's loads and the barrier, instead of behind
+        // the fragment build: the first round's data start to move 1 - 2 us earlier (fe_div.h; profiles/r05/div_prologue_phases.txt).
+        if constexpr (!ALDS && !W8) {
+            const int64_t first_ = (int64_t)bid * G::WAVES + wave;
+            if (wave * (int)sizeof(WaveLds) >= G::OP_D * 8 && first_ < nTiles) {
+                const unsigned lv = lds_addr_uniform(L->v[0]), lj = lds_addr_uniform(L->j);
+                fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first_, lane, lv, lj, jfe_flags);
+                fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first_, lane, lv + G::UNIT_D * 8, lj, jfe_flags);
+                first_requested = true;
+            }
+        }
         // operator layouts: 0 R[f][i][j], 1 L[i][f][j], 2 R[f][j][i], 3 L[j][f][i] -> strides of f, i, j
         const int sF = rlayout == 0 ? NP * NFP : rlayout == 1 ? NFP : rlayout == 2 ? NFP * NP : NP;
         const int sI = rlayout == 0 ? NFP : rlayout == 1 ? NF * NFP : 1;
@@ -327,9 +340,11 @@ __device__ __forceinline__ void facemass_mfma_body(
         return;
     }
 
-    // prologue: units 0 and 1 of the first tile
-    fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe_flags);
-    fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe_flags);
+    // prologue: units 0 and 1 of the first tile (unless requested in front of the fragment build)
+    if (!first_requested) {
+        fm_issue_unit_loads<NP, NFP, M, true, NF, ALDS, W8>(J, P.v[0], E, first, lane, lds_v0, lds_j, jfe_flags);
+        fm_issue_unit_loads<NP, NFP, M, false, NF, ALDS, W8>(J, P.v[1], E, first, lane, lds_v0 + G::UNIT_D * 8, lds_j, jfe_flags);
+    }
     if constexpr (kPrep) prepared_fragments_landed();
 
     int slot = 0;
