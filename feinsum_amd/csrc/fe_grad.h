@@ -304,7 +304,7 @@ __device__ __forceinline__ void grad3d_mfma_body(
     auto phys = [&](int64_t t) -> int64_t { return x_split_walk ? ((t & 1) ? half_tiles + (t >> 1) : (t >> 1)) : t; };
     const bool dyn = kDyn && tail != nullptr && t_static < nTiles;   // grid-uniform
     bool pre = false;   // unit 1 already requested
-    // the loads of this wave's first two units (behind the operator copy / the fragment loads)
+    // the loads of this wave's first unit -- and, with several fields, of the second field's u -- behind the operator copy / the fragment loads
     auto issue_first_units = [&]() -> int {   // returns the number of vector-memory ops that may stay in flight
         if (!(tile < tEnd) || x_no_loads) return 0;
         grad_issue_u<NP, M, kNT>(P.u[0], phys(tile), lane, lds_addr_uniform(L->u[0]), tload);
@@ -314,12 +314,9 @@ __device__ __forceinline__ void grad3d_mfma_body(
             pre = true;
             return 1;
         }
-        if (tile + stride < (dyn ? t_static : tEnd)) {
-            grad_issue_u<NP, M, kNT>(P.u[0], phys(tile + stride), lane, lds_addr_uniform(L->u[1]), tload);
-            grad_issue_j<NP, M, kPlain>(P, E, phys(tile + stride), lane, lds_addr_uniform(L->j[1]));
-            pre = true;
-            return 2;
-        }
+        // (one field: the SECOND tile is requested at the top of the first step, one tile ahead like every other -- until round 5 it
+        //  went out here as well, and the other block's operator, vector-memory data returning in order per CU, waited behind twice
+        //  the tile data: E = 1e5 22.4 -> 21.9 us, 1.4e5 -3.7 %, 5e5 -1 %, 1.31e5 +1 %: profiles/r05/grad_second_tile_requested_later_abl.txt)
         return 3;
     };
     // The elements behind the last full tile (fe_common.h: remainder_items), entry by entry on the VALU -- with the operator read from
@@ -632,7 +629,6 @@ __device__ __forceinline__ void grad3d_mfma_body(
         const int units_issued = issue_first_units();
         switch (units_issued) {
             case 1: wait_vmcnt<G::LOADS + G::U_INSTR>(); break;
-            case 2: wait_vmcnt<2 * G::LOADS>(); break;
             case 3: wait_vmcnt<G::LOADS>(); break;
             default: wait_vmcnt<0>(); break;
         }
