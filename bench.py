@@ -784,7 +784,7 @@ def main() -> None:
                    "tiles": launch_info.get("tiles"), "static_tiles": launch_info.get("static_tiles"),
                    "grid": [launch_info.get("blocks"), launch_info.get("waves_per_block")], "kernel": launch_info.get("kind"),
                    # (short launches: the ragged last round as quarter tiles; div's B build inside its matrix phase -- fe_last_launch_info)
-                   "quarter_tile_tail": bool(launch_info.get("quarter_tail")), "interleaved_b_build": bool(launch_info.get("interleaved")),
+                   "quarter_tile_tail": bool(launch_info.get("quarter_tail")), "staggered_start": bool(launch_info.get("staggered_start")), "interleaved_b_build": bool(launch_info.get("interleaved")),
                    "rule": "tickets in launches of four and a half or more rounds (fe_set_tail_rounds: %s)" % ("all" if rounds_setting >= (1 << 20) else rounds_setting),
                    # (the A/B is a different launch only when the timed one walked dynamically)
                    "kernel_ms_static_walk": None if (static_walk_ms is None or not dyn) else round(static_walk_ms, 5)}

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "fe_prepare_operator", "fe_grad3d_prepared_f64", "fe_div3d_prepared_f64", "fe_facemass_prepared_f64",
     "fe_graddiv3d_prepared_f64", "fe_waveop3d_prepared_f64", "fe_divcomp_f64", "fe_release_prepared",
     "fe_split_alloc", "fe_split_free", "fe_split_info", "fe_split_stats", "fe_split_reserve", "fe_split_trim", "fe_launch_f32", "fe_set_tail_rounds", "fe_set_tail_min_rounds",
-    "fe_set_cu_limit", "fe_set_phase_priority_p5", "fe_set_div_interleave", "fe_set_div_quarter_tail", "fe_set_grad_quarter_tail", "fe_last_launch_info", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
+    "fe_set_cu_limit", "fe_set_phase_priority_p5", "fe_set_div_interleave", "fe_set_div_quarter_tail", "fe_set_grad_quarter_tail", "fe_set_grad_staggered_start", "fe_last_launch_info", "fe_stream_retired", "fe_capture_id", "fe_graph_retired", "fe_tail_stats", "fe_tail_check", "fe_tail_plant", "fe_set_temporal_loads_mib", "fe_set_write_through_mib",
 )
 FAMILY_F32 = 0x100    # FE_FAMILY_F32
 
@@ -187,6 +187,8 @@ def load_library() -> C.CDLL:
     lib.fe_set_div_quarter_tail.argtypes = [C.c_int32]
     lib.fe_set_grad_quarter_tail.restype = C.c_int
     lib.fe_set_grad_quarter_tail.argtypes = [C.c_int32]
+    lib.fe_set_grad_staggered_start.restype = C.c_int
+    lib.fe_set_grad_staggered_start.argtypes = [C.c_int32]
     lib.fe_set_div_interleave.restype = C.c_int64
     lib.fe_set_div_interleave.argtypes = [C.c_int64]
     lib.fe_stream_retired.restype = C.c_int
@@ -517,6 +519,7 @@ def last_launch_info() -> dict:
         return {}
     d["interleaved"] = bool(d["kind"] & 4)
     d["quarter_tail"] = bool(d["kind"] & 8)
+    d["staggered_start"] = bool(d["kind"] & 16)
     d["kind"] = "B build interleaved" if d["kind"] & 4 else "default"
     return d
 
@@ -536,6 +539,12 @@ def set_grad_quarter_tail(on: bool) -> bool:
     """The ragged last round of short grad launches (one field, static walk) as quarter tiles (fe_set_grad_quarter_tail); returns
     the previous setting."""
     return bool(load_library().fe_set_grad_quarter_tail(int(on)))
+
+
+def set_grad_staggered_start(on: bool) -> bool:
+    """Short grad launches (one field, static walk, 2.5 to 4.5 rounds) start every second CU of an XCD half a tile period late
+    (fe_set_grad_staggered_start); returns the previous setting."""
+    return bool(load_library().fe_set_grad_staggered_start(1 if on else 0))
 
 
 def set_div_interleave(tiles: int) -> int:

@@ -116,6 +116,14 @@ constexpr int kOpPhasePriority = 64;
 // last full round -- at most an eighth of a round of them -- are processed as QUARTER tiles of four elements, one per wave, on
 // v_mfma_f64_4x4x4_4b (fe_div.h, fe_grad.h).
 constexpr int kOpQuarterTail = 128;
+// kOpStaggeredStart (round 5; the grad kernel under the static walk, one field, 2.5 to 4.5 rounds of tiles): the blocks on the odd
+// CUs of every XCD (block index / 8 odd: blocks go round the eight XCDs) sleep kStaggerSleeps x s_sleep 16 = 5120 cycles, about
+// half a SIMD's tile period, before their first instruction.  With every CU in step the older waves of all 256 CUs issue their
+// first stores within one microsecond (10 - 13 TB/s requested) and the younger waves' stage 2 waits behind them; out of step the
+// two halves of the chip alternate.  E = 8.2e4 ... 1.47e5: -0.5 ... -4 %; below 2.5 rounds the late half is the launch's end
+// (E = 5e4: +5 %), under the dynamic walk and at E = 1e6 it costs 1 - 3 %, div gains nothing (profiles/r05/staggered_start_abl.txt).
+constexpr int kOpStaggeredStart = 256;
+constexpr int kStaggerSleeps = 5;
 // One 16-byte write-through store per lane, in the addressing form the compiler gives its own stores (wave-uniform base in
 // SGPRs + one 32-bit lane offset + immediate): with a 64-bit VGPR address per store the same instruction cost 3 - 12 %.
 // (a macro: the immediate must be a constant where the statement stands -- inside an unrolled loop it is one after unrolling)

@@ -251,6 +251,10 @@ __device__ __forceinline__ void grad3d_mfma_body(
 #ifdef FE_EXPERIMENTS
     const unsigned long long t_entry = (kDbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
+    if constexpr (kPlain && !kPrep && !kDyn && M == 1) {   // (fe_common.h: every second CU of an XCD starts half a tile period late)
+        if ((op_flags & kOpStaggeredStart) && ((bid >> 3) & 1))
+            for (int i = 0; i < kStaggerSleeps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* L = reinterpret_cast<WaveLds*>(smem) + wave;

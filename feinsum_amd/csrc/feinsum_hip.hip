@@ -410,6 +410,14 @@ int grad_quarter_flag(int m, int nb, int64_t nTiles, int64_t waves) {
     return (m == 1 && nb == 1 && setting != 0 && nTiles > waves && ragged > 0 && den * ragged <= waves) ? fe::kOpQuarterTail : 0;
 }
 
+// ... and whether the odd CUs of every XCD start such a launch half a tile period late (fe_common.h, kOpStaggeredStart):
+// $FEINSUM_GRAD_STAGGERED_START / fe_set_grad_staggered_start.  The rule: tetrahedra p = 4, one field, a full grid, at least 2.5
+// rounds of tiles (the static walk ends at 4.5 rounds by itself).
+std::atomic<int> g_grad_staggered_start{[] { const char* e = getenv("FEINSUM_GRAD_STAGGERED_START"); return e ? atoi(e) : 1; }()};
+int grad_stagger_flag(int np, int m, int nb, int64_t nTiles, int64_t waves) {
+    return (np == 35 && m == 1 && nb == 1 && g_grad_staggered_start.load(std::memory_order_relaxed) && 2 * nTiles >= 5 * waves) ? fe::kOpStaggeredStart : 0;
+}
+
 // the same flag for the eight-wave p = 5 kernels (compute bound at every size): $FEINSUM_PHASE_PRIORITY_P5 / fe_set_phase_priority_p5
 std::atomic<int> g_phase_priority_p5{[] { const char* e = getenv("FEINSUM_PHASE_PRIORITY_P5"); return e ? atoi(e) : 0; }()};
 int phase_priority_flag_p5() { return g_phase_priority_p5.load(std::memory_order_relaxed) ? fe::kOpPhasePriority : 0; }
@@ -756,9 +764,11 @@ int launch_grad(const fe::GradFields& P, bool plain, const double* D, const void
                     }
                 }
             }
-            if (nb == 1) opT |= write_through_flag(3 * (int64_t)NP * E * 8) | grad_quarter_flag(M, nb, nTiles, (int64_t)g.x * G::WAVES);   // (static walk, one field: a short launch)
+            if (nb == 1)   // (static walk, one field: a short launch)
+                opT |= write_through_flag(3 * (int64_t)NP * E * 8) | grad_quarter_flag(M, nb, nTiles, (int64_t)g.x * G::WAVES) |
+                       grad_stagger_flag(NP, M, nb, nTiles, (int64_t)g.x * G::WAVES);
             FE_GRAD_CASE(0);
-            note_launch(false, opT, g.x, G::WAVES, nTiles, nTiles, (opT & fe::kOpQuarterTail) ? 8 : 0);
+            note_launch(false, opT, g.x, G::WAVES, nTiles, nTiles, ((opT & fe::kOpQuarterTail) ? 8 : 0) | ((opT & fe::kOpStaggeredStart) ? 16 : 0));
             break;
     }
 #undef FE_GRAD_CASE
@@ -2220,6 +2230,10 @@ int fe_set_div_quarter_tail(int32_t on) {
 
 int fe_set_grad_quarter_tail(int32_t on) {
     return g_grad_quarter_tail.exchange(on < 0 ? 0 : (on == 2 || on == 3) ? 1 : on);
+}
+
+int fe_set_grad_staggered_start(int32_t on) {
+    return g_grad_staggered_start.exchange(on ? 1 : 0);
 }
 
 int fe_set_tail_min_rounds(int32_t rounds) {

@@ -453,7 +453,7 @@ int fe_set_write_through_mib(int32_t mib);
 /* What the launcher decided for the MFMA launch this THREAD enqueued last (p = 1..4 grad / div / face-mass and the fused
  * launches; other paths leave it unchanged): out[0..n) = {valid, dynamic walk (tickets behind the static rounds), plain
  * (temporal) loads of the streamed operand, write-through stores, blocks, waves per block, kernel kind (bit 2: div with the
- * interleaved B build; bit 3: div or grad with a quarter-tile tail), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
+ * interleaved B build; bit 3: div or grad with a quarter-tile tail; bit 4: grad with a staggered start), bodies of a fused launch, tiles (summed over the bodies), statically walked tiles}.  Returns the number
  * written.  For reports (bench.py prints these instead of re-deriving the launcher's rules). */
 #define FE_LAST_LAUNCH_INFO 10
 int fe_last_launch_info(int64_t* out, int32_t n);
@@ -471,6 +471,11 @@ int fe_set_div_quarter_tail(int32_t on);
  * FEINSUM_GRAD_QUARTER_TAIL; a value n >= 4 widens the rule from an eighth to 1/n of a round, for measurements: a quarter of a
  * round loses 1 - 5 %).  Returns the previous setting.  Bitwise the results of the full tiles. */
 int fe_set_grad_quarter_tail(int32_t on);
+/* Short grad launches of one field on the static walk (tetrahedra p = 4, 2.5 to 4.5 rounds of tiles): the blocks on every second
+ * CU of an XCD start about 2.4 us -- half a SIMD's tile period -- late, so that the chip's two halves do not issue their stores
+ * in step (default on: E = 8.2e4 ... 1.47e5 -0.5 ... -4 %; also FEINSUM_GRAD_STAGGERED_START).  Returns the previous setting.
+ * Results do not depend on it. */
+int fe_set_grad_staggered_start(int32_t on);
 /* Phase priorities in the eight-wave kernels of tetrahedra p = 5 (grad, div): the waves' f64 VALU phases at raised issue
  * priority, their matrix phases at priority 0 (default off: -1 % for div at E >= 1e6, +-1 % for grad; also
  * FEINSUM_PHASE_PRIORITY_P5).  Returns the previous setting.  Results do not depend on it. */

@@ -993,6 +993,45 @@ def test_grad_with_a_quarter_tile_tail(torch_cuda, name, E):
         _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})
 
 
+@pytest.mark.parametrize("name", ["grad", "grad_t"])
+@pytest.mark.parametrize("E", [100000, 131072 + 5, 81920, 81904, 160000])
+def test_grad_with_a_staggered_start(torch_cuda, name, E):
+    """Round 5: a short grad launch of one field (static walk, at least 2.5 rounds of tiles) starts the blocks on every second CU of
+    an XCD half a tile period late (fe_grad.h, kOpStaggeredStart; fe_set_grad_staggered_start).  Timing only: BITWISE the launch
+    with every block in step, and the launcher reports what it decided -- 81 920 elements are exactly 2.5 rounds (on), 81 904 one
+    tile less (off), 160 000 walk dynamically (off)."""
+    torch = torch_cuda
+    expr = {"grad": dg.grad, "grad_t": dg.grad_t}[name]()
+    host = generate_host_input_arrays(expr, E, np_seed=E + 13)
+    before = _hip.set_grad_staggered_start(True)
+    try:
+        got = _run(torch, expr, host)
+        info = _hip.last_launch_info()
+        _hip.set_grad_staggered_start(False)
+        plain = _run(torch, expr, host)
+        info_plain = _hip.last_launch_info()
+    finally:
+        _hip.set_grad_staggered_start(before)
+    assert before is True                                      # the default
+    full_grid = info["blocks"] * info["waves_per_block"] == 2048
+    if full_grid:
+        assert bool(info.get("staggered_start")) == (E in (100000, 131072 + 5, 81920)), info
+        assert bool(info["dynamic_walk"]) == (E == 160000), info
+    assert not info_plain.get("staggered_start"), info_plain
+    for k in got:
+        assert np.array_equal(got[k], plain[k]), (name, E, k)
+    idx = np.unique(np.concatenate([np.arange(0, 48), np.arange(E // 2, E // 2 + 48), np.arange(E - 48, E)]))
+    sub = {}
+    for a in sorted(expr.all_args):
+        shape = expr.arg_to_shape[a]
+        ax = [i for i, d in enumerate(shape) if isinstance(d, f.SizeParam)]
+        sub[a] = np.take(host[a], idx, axis=ax[0]) if ax else host[a]
+    ref = _oracle(expr, sub)
+    ax = [i for i, d in enumerate(expr.shape) if isinstance(d, f.SizeParam)][0]
+    for k in got:
+        _assert_close({k: np.ascontiguousarray(np.take(got[k], idx, axis=ax))}, {k: ref[k]})
+
+
 @pytest.mark.parametrize("E", [98304, 100000, 131072])
 def test_the_reference_regime_sizes_against_the_oracle(torch_cuda, E):
     """The reference's own size regime (``long_dim_length`` defaults to 100 000: src/feinsum/measure.py:202; every fact of its
