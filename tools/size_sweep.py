@@ -48,7 +48,7 @@ for what in names:
         t = sorted(op.time_batch(n) / n for _ in range(5))[2]
         info = _hip.last_launch_info()
         chose = ", ".join(k for k, on in (("tickets", info.get("dynamic_walk")), ("plain loads", info.get("temporal_loads")),
-                                          ("write-through stores", info.get("write_through_stores")), ("quarter tiles", info.get("quarter_tail")),
+                                          ("write-through stores", info.get("write_through_stores")), ("quarter tiles", info.get("quarter_tail")), ("staggered start", info.get("staggered_start")),
                                           ("interleaved build", info.get("interleaved"))) if on) or "static walk, non-temporal"
         print(f"{what:8s} E={E:8d}: {t * 1e6:8.2f} us = {nbytes / t / 8e12:.3f} of the roofline   [{chose}]", flush=True)
         del op, outs, stages
