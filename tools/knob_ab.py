@@ -3,7 +3,7 @@
 A/B in one process on the SAME arrays of a launcher knob against its off state (round 5's knob=phase -- phase priorities on the
 p = 4 kernels -- was measured with this tool and removed: profiles/r05/phase_priorities_ab.txt).
 
-    python tools/knob_ab.py [grad div graddiv pipeline] [E ...] [knob=ilv|quarter|gquarter|tickets3|tickets2] [ilv=on]
+    python tools/knob_ab.py [grad div graddiv pipeline] [E ...] [knob=ilv|quarter|gquarter|gstagger|tickets3|tickets2] [ilv=on]
 
 knob=ilv: div launches on the kernel whose B build is interleaved into the matrix phase (fe_set_div_interleave) instead;
 knob=tickets3 / tickets2: the dynamic walk from three / two full rounds on (fe_set_tail_min_rounds); ilv=on: with the interleaved div.
@@ -21,9 +21,9 @@ from feinsum_amd import _hip, measure  # noqa: E402
 
 ALL = ("grad", "div", "graddiv", "pipeline")
 knob = ([a.split("=")[1] for a in sys.argv[1:] if a.startswith("knob=")] or ["ilv"])[0]
-setter = {"ilv": _hip.set_div_interleave, "quarter": lambda v: _hip.set_div_quarter_tail(bool(v)), "gquarter": lambda v: _hip.set_grad_quarter_tail(bool(v)), "gquarter4": lambda v: _hip.set_grad_quarter_tail(4 if v else 1),
+setter = {"ilv": _hip.set_div_interleave, "quarter": lambda v: _hip.set_div_quarter_tail(bool(v)), "gquarter": lambda v: _hip.set_grad_quarter_tail(bool(v)), "gquarter4": lambda v: _hip.set_grad_quarter_tail(4 if v else 1), "gstagger": lambda v: _hip.set_grad_staggered_start(bool(v)),
           "tickets3": lambda v: _hip.set_tail_min_rounds(3 if v else 4), "tickets2": lambda v: _hip.set_tail_min_rounds(2 if v else 4)}[knob]
-label = {"ilv": "interleaved B build", "quarter": "quarter-tile tail", "gquarter": "quarter-tile tail (grad)", "gquarter4": "quarter tiles up to a quarter round", "tickets3": "tickets from three rounds", "tickets2": "tickets from two rounds"}[knob]
+label = {"ilv": "interleaved B build", "quarter": "quarter-tile tail", "gquarter": "quarter-tile tail (grad)", "gquarter4": "quarter tiles up to a quarter round", "gstagger": "every second CU of an XCD starts late (grad)", "tickets3": "tickets from three rounds", "tickets2": "tickets from two rounds"}[knob]
 if "ilv=on" in sys.argv:       # (other knobs measured with the interleaved div in place)
     _hip.set_div_interleave(1 << 40)
 args = [a for a in sys.argv[1:] if not a.startswith("knob=") and a != "ilv=on"]
